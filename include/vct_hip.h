@@ -1,0 +1,174 @@
+/*
+ * vct_hip.h -- C ABI of libvct_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * video-caption Transformer training / greedy-decode path.
+ *
+ * The reference (Kamino666/Video-Captioning-Transformer) has no FFI for this path: every FLOP is a
+ * stock torch.nn module call.  Each entry point below therefore cites the reference call site
+ * (file:line under /root/reference) and the torch operator whose arithmetic it replaces.  A
+ * reference maintainer binds them with ctypes; nothing here knows about torch.
+ *
+ * Conventions
+ *  - every function returns int: 0 ok, <0 argument/shape error (VCT_E_*), >0 a hipError_t;
+ *    nothing throws, nothing allocates, nothing synchronises the host: all work is enqueued on the
+ *    caller's `stream` (a hipStream_t passed as void*), so every call is hipGraph-capturable.
+ *  - all pointers are DEVICE pointers owned by the caller; tensors are row-major; "ld*" are leading
+ *    dimensions in ELEMENTS.  Activations are VCT_F32 or VCT_BF16 ("compute dtype"); statistics,
+ *    biases, LayerNorm parameters, losses and every parameter gradient are fp32.
+ *  - leading dimensions of VCT_BF16 matrices must be multiples of 8 elements and base pointers
+ *    16-byte aligned (VCT_F32: multiples of 4).  A K extent that is not a multiple of 8 (4) along a
+ *    contiguous dimension must be zero-padded up to it by the producer (the SCE-loss kernel does
+ *    this for the vocabulary dimension).
+ *  - dropout: mask(site, idx) = hash(seed[0], site, idx) >= p * 2^32, scaled by 1/(1-p); `seed` is
+ *    a DEVICE pointer (so a captured graph sees a new seed each replay); p == 0 or seed == NULL
+ *    disables it.  The backward kernels recompute the same mask from (site, idx).
+ */
+#ifndef VCT_HIP_H
+#define VCT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCT_ABI_VERSION 1
+
+enum { VCT_F32 = 0, VCT_BF16 = 1 };
+enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
+enum {
+  VCT_OK = 0,
+  VCT_E_ARG = -1,      /* null pointer / bad enum */
+  VCT_E_SHAPE = -2,    /* unsupported or inconsistent shape */
+  VCT_E_ALIGN = -3,    /* leading dimension / pointer alignment */
+  VCT_E_WORKSPACE = -4 /* workspace too small */
+};
+
+int vct_abi_version(void);
+/* writes "gfx950 ..." build string; returns its length */
+int vct_build_info(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM family: C[M,N] = epilogue(op(A)[M,K] * op(B)[K,N])   -- MFMA (bf16 16x16x32 / f32 16x16x4)
+ *   ta == 0: A stored [M,K] (K contiguous)      ta == 1: A stored [K,M] (M contiguous)
+ *   tb == 1: B stored [N,K] (nn.Linear weight)  tb == 0: B stored [K,N] (N contiguous)
+ * replaces: nn.Linear forward (MMEncoder.py:246, CapDecoder.py:55, the linear1/linear2/in_proj/out_proj
+ * inside nn.Transformer{En,De}coderLayer -- torch nn/modules/transformer.py:951-982,1143-1199 and
+ * nn/functional.py:5785,6637) and its autograd backward (dX = dY*W: ta=0,tb=0; dW = dY^T*X: ta=1,tb=0).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_gemm_desc {
+  int32_t dtype;      /* VCT_F32 | VCT_BF16 : element type of A and B */
+  int32_t out_dtype;  /* element type of C, preact, addend */
+  int32_t ta, tb;
+  int32_t M, N, K;
+  int32_t act;        /* VCT_ACT_*: applied after bias */
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;                        /* [N] or NULL */
+  void* preact; int64_t ld_preact;          /* optional: acc+bias before act (saved for backward) */
+  const void* addend; int64_t ld_addend;    /* optional: C += addend (residual-gradient accumulate) */
+  const void* dact_src; int64_t ld_dact;    /* optional: C = acc * act'(dact_src) (type = out_dtype) */
+  const uint32_t* seed; uint32_t site; float p_drop; /* dropout on C (after act / inside dact) */
+  float* bias_grad;                         /* optional [M] fp32: sum over K of op(A) (db for ta=1) */
+  void* workspace; int64_t workspace_bytes; /* split-K partials (fp32); NULL = never split */
+  int32_t split_k;                          /* 0 auto, 1 none, >1 forced */
+  int32_t reserved;
+} vct_gemm_desc;
+int vct_gemm(const vct_gemm_desc* d, void* stream);
+/* bytes of workspace vct_gemm may use for this descriptor (0 if it will not split) */
+int64_t vct_gemm_workspace_bytes(const vct_gemm_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention core: O = softmax(Q K^T / sqrt(hd) + mask) V per (batch, head), one wave each,
+ * QK^T and PV as MFMA tiles, K/V staged in LDS, row softmax by wave shuffles, dropout on P.
+ * replaces: F.scaled_dot_product_attention + mask merge inside nn.MultiheadAttention
+ * (torch nn/functional.py:6553-6570,6629) as used at MMEncoder.py:274, CapDecoder.py:49-52,70-75.
+ *   q: rows b*Lq+i, cols h*hd..; k,v: rows b*Lk+j.  ld in elements.  causal: key j > query i masked.
+ *   key_pad: uint8 [B,Lk], 1 = padded key (masked) or NULL.  Limits: Lq, Lk <= 64, hd <= 128.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_attn_desc {
+  int32_t dtype;
+  int32_t B, H, Lq, Lk, hd;
+  int32_t causal;
+  int32_t reserved;
+  const void* q; int64_t ldq;
+  const void* k; int64_t ldk;
+  const void* v; int64_t ldv;
+  void* o; int64_t ldo;
+  const uint8_t* key_pad;
+  const uint32_t* seed; uint32_t site; float p_drop;
+  /* backward only */
+  const void* d_o; int64_t ld_do;
+  void* dq; int64_t ld_dq;
+  void* dk; int64_t ld_dk;
+  void* dv; int64_t ld_dv;
+} vct_attn_desc;
+int vct_attn_fwd(const vct_attn_desc* d, void* stream);
+int vct_attn_bwd(const vct_attn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).
+ * replaces: dropoutN + residual add + nn.LayerNorm (torch nn/modules/transformer.py:951-957,
+ * 1143-1153) and the stack-final norms (MMEncoder.py:238, CapDecoder.py:20).
+ * mean/rstd: fp32 [M] saved for backward.
+ * bwd: ds = dLN(dy) (gradient of the pre-norm sum), dxo = dropout-masked ds (may alias ds when p==0,
+ * may be NULL when res == NULL and p == 0); dgamma/dbeta fp32 [d] (overwritten), param_ws fp32
+ * [2 * vct_ln_ws_rows(M) * d] scratch.
+ * --------------------------------------------------------------------------------------------- */
+int vct_add_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma,
+                   const float* beta, void* y, float* mean, float* rstd, const uint32_t* seed,
+                   uint32_t site, float p_drop, void* stream);
+int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,
+                   const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
+                   float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
+                   float p_drop, void* stream);
+int vct_ln_ws_rows(int M);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder front end after the `unify` GEMM: z[b,0] = mean_t u[b,t] (all T rows, pads included),
+ * z[b,t+1] = u[b,t] + pe_rows[t+1]  (pe_rows fp32 [T+1,d], row 0 = 0).
+ * replaces: GlobalAggregation('avg') + cat + TemporalEncoding add (MMEncoder.py:196-197,248-250,
+ * 89-104,271).  bwd: du[b,t] = dz[b,t+1] + dz[b,0]/T.
+ * --------------------------------------------------------------------------------------------- */
+int vct_enc_frontend_fwd(int dtype, int B, int T, int d, const void* u, const float* pe_rows, void* z,
+                         void* stream);
+int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* dz, void* du, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token embedding: x[n] = dropout(table[ids[n]] + pos[n % S])   (no sqrt(d) scaling)
+ * replaces: nn.Embedding(padding_idx) + PositionalEmbedding (CapDecoder.py:26,48; Embedding.py:23-25).
+ * ids: int64 [N] read with element stride id_stride from ids + b*id_batch_stride (so the token-shift
+ * view tgt[:, :-1] needs no copy): token n = (b = n / S, s = n % S) -> ids[b*id_batch_stride + s].
+ * bwd: dtable fp32 [V,d] = scatter-add of dx rows (deterministic order), row pad_id zero.
+ * --------------------------------------------------------------------------------------------- */
+int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids, int64_t id_batch_stride,
+                  const void* table, const float* pos, void* x, const uint32_t* seed, uint32_t site,
+                  float p_drop, void* stream);
+int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
+                  int64_t pad_id, const void* dx, float* dtable, const uint32_t* seed, uint32_t site,
+                  float p_drop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Symmetric cross-entropy loss + gradient w.r.t. logits, one workgroup per row, row held in LDS.
+ * replaces: SCELoss.forward (loss.py:78-92) / nn.CrossEntropyLoss(ignore_index) when alpha == 1
+ * (CapDecoder.py:28-32,56-59) and their autograd backward.
+ *   logits [N, ldl] (V valid columns); labels int64: row n = (b = n / S, s = n % S) ->
+ *   labels[b*label_batch_stride + s]  (so tgt[:, 1:] needs no copy).
+ *   loss_out fp32 [1]; dlogits (may alias logits; columns V..ldl-1 are written as 0) or NULL.
+ *   row_ws fp32 [2*N + 2] scratch.
+ * --------------------------------------------------------------------------------------------- */
+int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, int64_t ldl, const int64_t* labels,
+                 int64_t label_batch_stride, int64_t pad_id, float alpha, float* loss_out, void* dlogits,
+                 int64_t ld_dl, float* row_ws, void* stream);
+
+/* elementwise helpers ------------------------------------------------------------------------ */
+/* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */
+int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* first-index argmax per row (torch.max(dim=1) tie-break, MMT4Caption.py:165); out int64 [rows] */
+int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, void* stream);
+/* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
+int vct_advance_seed(uint32_t* seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCT_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libvct_hip.so (include/vct_hip.h).  The product path has NO fallback: if the
+library is missing or a call fails this module raises."""
+import ctypes as C
+import os
+
+import torch  # must be imported first: libvct_hip.so binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
+_ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
+        -3: "VCT_E_ALIGN (leading dimension / alignment)", -4: "VCT_E_WORKSPACE (workspace too small)"}
+
+vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("out_dtype", i32), ("ta", i32), ("tb", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("act", i32), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
+                ("bias", vp), ("preact", vp), ("ld_preact", i64), ("addend", vp), ("ld_addend", i64),
+                ("dact_src", vp), ("ld_dact", i64), ("seed", vp), ("site", u32), ("p_drop", f32),
+                ("bias_grad", vp), ("workspace", vp), ("workspace_bytes", i64), ("split_k", i32), ("reserved", i32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("hd", i32), ("causal", i32),
+                ("reserved", i32), ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64),
+                ("o", vp), ("ldo", i64), ("key_pad", vp), ("seed", vp), ("site", u32), ("p_drop", f32),
+                ("d_o", vp), ("ld_do", i64), ("dq", vp), ("ld_dq", i64), ("dk", vp), ("ld_dk", i64),
+                ("dv", vp), ("ld_dv", i64)]
+
+
+_SIGS = {
+    "vct_abi_version": (C.c_int, []),
+    "vct_build_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "vct_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "vct_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
+    "vct_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_ln_ws_rows": (C.c_int, [C.c_int]),
+    "vct_enc_frontend_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "vct_enc_frontend_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "vct_embed_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, u32, f32, vp]),
+    "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
+    "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
+    "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "vct_advance_seed": (C.c_int, [vp, vp]),
+}
+# entry points added by later source files (optional until those files exist in the build)
+_OPTIONAL = {
+    "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i64, i64, vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/vct_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(list(_SIGS) + list(_OPTIONAL))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is the product path and has no CPU/eager fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    if lib.vct_abi_version() != 1:
+        raise RuntimeError("libvct_hip.so ABI version mismatch")
+    # one HIP runtime per process: our kernels must launch on torch's streams
+    try:
+        n = sum(1 for ln in open("/proc/self/maps") if "libamdhip64" in ln and " r-xp " in ln)
+        if n > 1:
+            raise RuntimeError("two copies of libamdhip64 are mapped; import torch before loading libvct_hip.so")
+    except OSError:
+        pass
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError(f"{what}: {_ERR.get(rc, rc)}")
+    raise RuntimeError(f"{what}: hipError_t {rc}")
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

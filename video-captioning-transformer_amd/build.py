@@ -1,0 +1,62 @@
+"""Build libvct_hip.so (all HIP kernels, gfx950) in-tree with hipcc.  No JIT cache, no torch
+extension machinery: the product boundary is a plain C-ABI shared library (include/vct_hip.h)."""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libvct_hip.so")
+SOURCES = ["vct_gemm.hip", "vct_attn.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_decode.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _digest():
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)) + ["../../include/vct_hip.h"]:
+        p = os.path.join(CSRC, fn)
+        if os.path.isfile(p):
+            h.update(fn.encode())
+            h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip for gfx950 and link libvct_hip.so next to this file."""
+    stamp = os.path.join(PKG, "build", "stamp")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def cc(src):
+        obj = os.path.join(PKG, "build", src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

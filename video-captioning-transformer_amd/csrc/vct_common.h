@@ -1,0 +1,130 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, MFMA fragment types, bf16 packing,
+// counter-hash dropout, wave/block reductions).  CDNA4 only -- no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vct_hip.h"
+
+namespace vct {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;  // storage type of a bf16 element
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// ---- activation ------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(int act, float x) {
+  return act == VCT_ACT_GELU ? gelu_f(x) : (act == VCT_ACT_RELU ? fmaxf(x, 0.0f) : x);
+}
+__device__ __forceinline__ float dact_f(int act, float x) {
+  return act == VCT_ACT_GELU ? dgelu_f(x) : (act == VCT_ACT_RELU ? (x > 0.0f ? 1.0f : 0.0f) : 1.0f);
+}
+
+// ---- dropout: counter hash (seed, site, element index) -> 32 random bits ----------------------
+// Stateless so the backward kernels regenerate the forward mask.  Two multiply-xorshift rounds
+// (murmur3 fmix32 with a golden-ratio pre-mix): plenty for a Bernoulli mask.
+struct Dropout {
+  uint32_t key;     // seed ^ site mix
+  uint32_t thresh;  // drop if hash < thresh
+  float scale;      // 1/(1-p)
+  bool on;
+};
+__device__ __forceinline__ Dropout make_dropout(const uint32_t* seed, uint32_t site, float p) {
+  Dropout d;
+  d.on = (seed != nullptr) && (p > 0.0f);
+  d.key = d.on ? (seed[0] * 0x9E3779B1u) ^ (site * 0x85EBCA77u + 0x165667B1u) : 0u;
+  d.thresh = d.on ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u;
+  d.scale = d.on ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+// multiplier to apply to element `idx` (0 or 1/(1-p)); 1 when dropout is off
+__device__ __forceinline__ float drop_mult(const Dropout& d, uint32_t idx) {
+  if (!d.on) return 1.0f;
+  const uint32_t h = hash32((idx * 0x9E3779B1u) ^ d.key);
+  return h < d.thresh ? 0.0f : d.scale;
+}
+
+// ---- reductions ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// block reductions over NW waves; `red` is LDS scratch of >= NW floats; all threads get the result
+template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NW; i++) s += red[i];
+  return s;
+}
+template <int NW> __device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float s = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) s = fmaxf(s, red[i]);
+  return s;
+}
+
+// ---- LDS transpose read (gfx950 ds_read_b64_tr_b16) -------------------------------------------
+// Within each 16-lane group: lane i supplies the address of 4 contiguous bf16; lane i receives, for
+// j = 0..3, element (i & 3) of the chunk supplied by lane 4*j + (i >> 2).  When lanes 4r..4r+3 point
+// at the four 8-byte chunks of row r of a [4][16] block, lane i ends up with column i (rows 0..3).
+// (Semantics confirmed on hardware by tools/hw_probe.hip.)
+__device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <typename T> struct DTypeOf;
+template <> struct DTypeOf<float> { static constexpr int v = VCT_F32; };
+template <> struct DTypeOf<bf16_t> { static constexpr int v = VCT_BF16; };
+
+}  // namespace vct
+
+#define VCT_CHECK_LAUNCH()                               \
+  do {                                                   \
+    hipError_t e__ = hipGetLastError();                  \
+    if (e__ != hipSuccess) return (int)e__;              \
+  } while (0)

@@ -1,0 +1,449 @@
+// HBM-bound pieces of the caption path on gfx950: encoder front end (mean token + temporal
+// encoding), token embedding gather / deterministic scatter-add, the symmetric-cross-entropy loss
+// with its logits gradient (row resident in LDS: one HBM read + one HBM write per logit), casts,
+// first-index arg-max, dropout seed advance.  All loads/stores are 16-byte vectors where the
+// layout allows; reductions use wave shuffles + a few LDS words.
+#include "vct_common.h"
+
+namespace vct {
+
+template <typename T> struct EV { static constexpr int VEC = 16 / sizeof(T); };
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) PackT { T v[VEC]; };
+
+// ---------------------------------------------------------------------------------------------
+// encoder front end: z[b,0,:] = mean_t u[b,t,:]; z[b,t+1,:] = u[b,t,:] + pe[t+1,:]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void enc_frontend_fwd_kernel(int B, int Tn, int d, const T* __restrict__ u, const float* __restrict__ pe,
+                                        T* __restrict__ z) {
+  constexpr int VEC = EV<T>::VEC;
+  using P = PackT<T, VEC>;
+  const int b = blockIdx.x;
+  const int nvec = d / VEC;
+  for (int vi = threadIdx.x; vi < nvec; vi += blockDim.x) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) acc[j] = 0.0f;
+    for (int t = 0; t < Tn; t++) {
+      const P uv = *reinterpret_cast<const P*>(u + ((size_t)b * Tn + t) * d + vi * VEC);
+      P o;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const float f = to_f<T>(uv.v[j]);
+        acc[j] += f;
+        o.v[j] = from_f<T>(f + pe[(size_t)(t + 1) * d + vi * VEC + j]);
+      }
+      *reinterpret_cast<P*>(z + ((size_t)b * (Tn + 1) + t + 1) * d + vi * VEC) = o;
+    }
+    P m;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) m.v[j] = from_f<T>(acc[j] / (float)Tn + pe[vi * VEC + j]);
+    *reinterpret_cast<P*>(z + ((size_t)b * (Tn + 1)) * d + vi * VEC) = m;
+  }
+}
+
+template <typename T>
+__global__ void enc_frontend_bwd_kernel(int B, int Tn, int d, const T* __restrict__ dz, T* __restrict__ du) {
+  constexpr int VEC = EV<T>::VEC;
+  using P = PackT<T, VEC>;
+  const int b = blockIdx.x;
+  const int nvec = d / VEC;
+  const float inv = 1.0f / (float)Tn;
+  for (int vi = threadIdx.x; vi < nvec; vi += blockDim.x) {
+    const P g0 = *reinterpret_cast<const P*>(dz + ((size_t)b * (Tn + 1)) * d + vi * VEC);
+    for (int t = 0; t < Tn; t++) {
+      const P g = *reinterpret_cast<const P*>(dz + ((size_t)b * (Tn + 1) + t + 1) * d + vi * VEC);
+      P o;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) o.v[j] = from_f<T>(to_f<T>(g.v[j]) + to_f<T>(g0.v[j]) * inv);
+      *reinterpret_cast<P*>(du + ((size_t)b * Tn + t) * d + vi * VEC) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token embedding (fp32 master table gathered directly: no bf16 copy of the 62.5 MB table needed)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(int N, int S, int d, const int64_t* __restrict__ ids,
+                                                        int64_t id_bstride, const float* __restrict__ table,
+                                                        const float* __restrict__ pos, T* __restrict__ x,
+                                                        const uint32_t* seed, uint32_t site, float p_drop) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const Dropout dr = make_dropout(seed, site, p_drop);
+  const int b = n / S, s = n % S;
+  const int64_t id = ids[(size_t)b * id_bstride + s];
+  const float4* trow = reinterpret_cast<const float4*>(table + (size_t)id * d);
+  const float4* prow = reinterpret_cast<const float4*>(pos + (size_t)s * d);
+  for (int vi = lane; vi < d / 4; vi += 64) {
+    const float4 tv = trow[vi], pv = prow[vi];
+    const float e[4] = {tv.x + pv.x, tv.y + pv.y, tv.z + pv.z, tv.w + pv.w};
+    PackT<T, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o.v[j] = from_f<T>(e[j] * drop_mult(dr, (uint32_t)n * (uint32_t)d + (uint32_t)(vi * 4 + j)));
+    *reinterpret_cast<PackT<T, 4>*>(x + (size_t)n * d + vi * 4) = o;
+  }
+}
+
+// Deterministic scatter-add: the block of token position n owns table row ids[n] iff n is the FIRST
+// position holding that id; it then sums dx rows of every later occurrence in increasing position
+// order.  No float atomics, bitwise reproducible.  dtable must be zero-filled beforehand.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, const int64_t* __restrict__ ids,
+                                                        int64_t id_bstride, int64_t pad_id, const T* __restrict__ dx,
+                                                        float* __restrict__ dtable, const uint32_t* seed, uint32_t site,
+                                                        float p_drop) {
+  __shared__ int s_dup;
+  __shared__ int s_cnt;
+  __shared__ int s_list[1024];
+  const int n = blockIdx.x;
+  const int b0 = n / S, s0 = n % S;
+  const int64_t id = ids[(size_t)b0 * id_bstride + s0];
+  if (id == pad_id) return;
+  if (threadIdx.x == 0) { s_dup = 0; s_cnt = 0; }
+  __syncthreads();
+  int dup = 0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) dup |= (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
+  if (dup) s_dup = 1;  // benign race: all writers store 1
+  __syncthreads();
+  if (s_dup) return;
+  const Dropout dr = make_dropout(seed, site, p_drop);
+  // later occurrences, processed in chunks of 1024 positions so the order stays increasing
+  float acc[8];
+  const int nd = d;  // thread t owns columns t, t+256, ...  (d <= 2048)
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0.0f;
+  for (int base = n; base < N; base += 1024) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    // ordered compaction of matches in [base, base+1024): ballot per wave, prefix over waves
+    for (int sub = 0; sub < 1024; sub += 256) {
+      const int j = base + sub + threadIdx.x;
+      const bool match = (j < N) && (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
+      const unsigned long long bal = __ballot(match);
+      __shared__ int s_wcnt[4];
+      const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+      if (l == 0) s_wcnt[w] = __popcll(bal);
+      __syncthreads();
+      int off = s_cnt;
+      for (int ww = 0; ww < w; ww++) off += s_wcnt[ww];
+      if (match) s_list[off + __popcll(bal & ((1ull << l) - 1ull))] = j;
+      __syncthreads();
+      if (threadIdx.x == 0) s_cnt += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      __syncthreads();
+    }
+    const int cnt = s_cnt;
+    for (int q = 0; q < cnt; q++) {
+      const int j = s_list[q];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = threadIdx.x + k * 256;
+        if (c < nd) acc[k] += to_f<T>(dx[(size_t)j * d + c]) * drop_mult(dr, (uint32_t)j * (uint32_t)d + (uint32_t)c);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int c = threadIdx.x + k * 256;
+    if (c < nd) dtable[(size_t)id * d + c] = acc[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SCE loss + dlogits.  One 1024-thread workgroup per row; the row sits in LDS as fp32.
+// ---------------------------------------------------------------------------------------------
+__global__ void count_valid_kernel(int N, int S, const int64_t* __restrict__ labels, int64_t lbstride, int64_t pad_id,
+                                   float* __restrict__ out) {
+  __shared__ float red[16];
+  float c = 0.0f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) c += (labels[(size_t)(n / S) * lbstride + (n % S)] != pad_id) ? 1.0f : 0.0f;
+  c = block_sum<16>(c, red);
+  if (threadIdx.x == 0) out[0] = c;
+}
+
+constexpr float SCE_C = 9.210340371976184f;  // -log(1e-4): loss.py:86-88 off-target log(clamp(onehot))
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sce_loss_kernel(int N, int S, int V, const T* __restrict__ logits, int64_t ldl,
+                                                        const int64_t* __restrict__ labels, int64_t lbstride,
+                                                        int64_t pad_id, float alpha, T* __restrict__ dlogits, int64_t ld_dl,
+                                                        float* __restrict__ row_ws) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  __shared__ float red[16];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const T* x = logits + (size_t)n * ldl;
+  const int64_t y = labels[(size_t)(n / S) * lbstride + (n % S)];
+  const bool valid = (y != pad_id);
+  const float nvalid = row_ws[2 * N];
+  // pass 1: stage the row, running max
+  float mx = -INFINITY;
+  for (int j = tid; j < V; j += 1024) {
+    const float v = to_f<T>(x[j]);
+    row[j] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max<16>(mx, red);
+  const float xy = row[y];  // visible: block_max synchronised
+  __syncthreads();
+  // pass 2: e = exp(x - max), sum
+  float se = 0.0f;
+  for (int j = tid; j < V; j += 1024) {
+    const float e = expf(row[j] - mx);
+    row[j] = e;
+    se += e;
+  }
+  se = block_sum<16>(se, red);
+  const float inv = 1.0f / se;
+  const float beta = 1.0f - alpha;
+  // pass 3: Q = sum_{j != y, p_j >= 1e-7} p_j ; cnt = #{j != y : p_j < 1e-7}
+  float q = 0.0f, cnt = 0.0f;
+  if (alpha != 1.0f) {
+    for (int j = tid; j < V; j += 1024) {
+      if (j != y) {
+        const float pj = row[j] * inv;
+        if (pj >= 1e-7f) q += pj; else cnt += 1.0f;
+      }
+    }
+    q = block_sum<16>(q, red);
+    cnt = block_sum<16>(cnt, red);
+  }
+  if (tid == 0) {
+    row_ws[n] = valid ? (mx + logf(se)) - xy : 0.0f;
+    row_ws[N + n] = SCE_C * (q + 1e-7f * cnt);
+  }
+  if (dlogits == nullptr) return;
+  // pass 4: gradient  a*(p - 1[j==y]) + (beta/N) * p * (G_j - c*Q),  G_j = c*[j != y][p_j >= 1e-7]
+  const float a = valid ? alpha / nvalid : 0.0f;
+  const float bn = (alpha != 1.0f) ? beta / (float)N : 0.0f;
+  T* dx = dlogits + (size_t)n * ld_dl;
+  for (int j = tid; j < (int)ld_dl; j += 1024) {
+    float gval = 0.0f;
+    if (j < V) {
+      const float pj = row[j] * inv;
+      const float G = (j != y && pj >= 1e-7f) ? SCE_C : 0.0f;
+      gval = a * (pj - (j == y ? 1.0f : 0.0f)) + bn * pj * (G - SCE_C * q);
+    }
+    dx[j] = from_f<T>(gval);
+  }
+}
+
+__global__ void sce_finalize_kernel(int N, float alpha, const float* __restrict__ row_ws, float* __restrict__ loss) {
+  __shared__ float red[16];
+  float ce = 0.0f, rce = 0.0f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) { ce += row_ws[n]; rce += row_ws[N + n]; }
+  ce = block_sum<16>(ce, red);
+  rce = block_sum<16>(rce, red);
+  if (threadIdx.x == 0) {
+    const float nvalid = row_ws[2 * N];
+    const float l_ce = ce / nvalid;
+    loss[0] = (alpha == 1.0f) ? l_ce : alpha * l_ce + (1.0f - alpha) * (rce / (float)N);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const PackT<TS, 4> s = reinterpret_cast<const PackT<TS, 4>*>(src)[i];
+    PackT<TD, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o.v[j] = from_f<TD>(to_f<TS>(s.v[j]));
+    reinterpret_cast<PackT<TD, 4>*>(dst)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    dst[i] = from_f<TD>(to_f<TS>(src[i]));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __restrict__ x, int64_t ldx,
+                                                          int64_t* __restrict__ out) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const T* r = x + (size_t)blockIdx.x * ldx;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = threadIdx.x; j < cols; j += 256) {
+    const float v = to_f<T>(r[j]);
+    if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
+    out[blockIdx.x] = (bi == 0x7fffffff) ? 0 : bi;
+  }
+}
+
+__global__ void advance_seed_kernel(uint32_t* seed) { seed[0] += 1u; }
+
+}  // namespace vct
+using namespace vct;
+
+static bool dt_ok(int dt) { return dt == VCT_F32 || dt == VCT_BF16; }
+static int vec_of(int dt) { return dt == VCT_BF16 ? 8 : 4; }
+
+extern "C" int vct_enc_frontend_fwd(int dtype, int B, int T, int d, const void* u, const float* pe_rows, void* z,
+                                    void* stream) {
+  if (!dt_ok(dtype) || !u || !pe_rows || !z) return VCT_E_ARG;
+  if (B <= 0 || T <= 0 || d <= 0) return VCT_E_SHAPE;
+  if (d % vec_of(dtype)) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = 128;
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((enc_frontend_fwd_kernel<bf16_t>), dim3(B), dim3(threads), 0, st, B, T, d, (const bf16_t*)u, pe_rows, (bf16_t*)z);
+  else
+    hipLaunchKernelGGL((enc_frontend_fwd_kernel<float>), dim3(B), dim3(threads), 0, st, B, T, d, (const float*)u, pe_rows, (float*)z);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* dz, void* du, void* stream) {
+  if (!dt_ok(dtype) || !dz || !du) return VCT_E_ARG;
+  if (B <= 0 || T <= 0 || d <= 0) return VCT_E_SHAPE;
+  if (d % vec_of(dtype)) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((enc_frontend_bwd_kernel<bf16_t>), dim3(B), dim3(128), 0, st, B, T, d, (const bf16_t*)dz, (bf16_t*)du);
+  else
+    hipLaunchKernelGGL((enc_frontend_bwd_kernel<float>), dim3(B), dim3(128), 0, st, B, T, d, (const float*)dz, (float*)du);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids, int64_t id_batch_stride,
+                             const void* table, const float* pos, void* x, const uint32_t* seed, uint32_t site,
+                             float p_drop, void* stream) {
+  if (!dt_ok(dtype) || !ids || !table || !pos || !x) return VCT_E_ARG;
+  if (B <= 0 || S <= 0 || d <= 0) return VCT_E_SHAPE;
+  if (d % 4) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * S;
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
+                       (const float*)table, pos, (bf16_t*)x, seed, site, p_drop);
+  else
+    hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
+                       (const float*)table, pos, (float*)x, seed, site, p_drop);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
+                             int64_t pad_id, const void* dx, float* dtable, const uint32_t* seed, uint32_t site,
+                             float p_drop, void* stream) {
+  if (!dt_ok(dtype) || !ids || !dx || !dtable) return VCT_E_ARG;
+  if (B <= 0 || S <= 0 || d <= 0 || V <= 0) return VCT_E_SHAPE;
+  if (d > 2048) return VCT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dtable, 0, (size_t)V * d * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const int N = B * S;
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
+                       (const bf16_t*)dx, dtable, seed, site, p_drop);
+  else
+    hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
+                       (const float*)dx, dtable, seed, site, p_drop);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, int64_t ldl, const int64_t* labels,
+                            int64_t label_batch_stride, int64_t pad_id, float alpha, float* loss_out, void* dlogits,
+                            int64_t ld_dl, float* row_ws, void* stream) {
+  if (!dt_ok(dtype) || !logits || !labels || !loss_out || !row_ws) return VCT_E_ARG;
+  if (N <= 0 || S <= 0 || V <= 0 || N % S) return VCT_E_SHAPE;
+  if ((size_t)V * 4 > 160 * 1024 - 256) return VCT_E_SHAPE;  // row must fit in one CU's LDS
+  if (ldl < V || (dlogits && ld_dl < V)) return VCT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, st, N, S, labels, label_batch_stride, pad_id, row_ws + 2 * (size_t)N);
+  VCT_CHECK_LAUNCH();
+  const size_t shmem = (size_t)V * 4;
+  if (dtype == VCT_BF16) {
+    auto kfn = sce_loss_kernel<bf16_t>;
+    static int attr_bf16 = 0;
+    if ((int)shmem > attr_bf16) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+      attr_bf16 = (int)shmem;
+    }
+    hipLaunchKernelGGL(kfn, dim3(N), dim3(1024), shmem, st, N, S, V, (const bf16_t*)logits, ldl, labels, label_batch_stride,
+                       pad_id, alpha, (bf16_t*)dlogits, ld_dl, row_ws);
+  } else {
+    auto kfn = sce_loss_kernel<float>;
+    static int attr_f32 = 0;
+    if ((int)shmem > attr_f32) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+      attr_f32 = (int)shmem;
+    }
+    hipLaunchKernelGGL(kfn, dim3(N), dim3(1024), shmem, st, N, S, V, (const float*)logits, ldl, labels, label_batch_stride,
+                       pad_id, alpha, (float*)dlogits, ld_dl, row_ws);
+  }
+  VCT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sce_finalize_kernel, dim3(1), dim3(1024), 0, st, N, alpha, row_ws, loss_out);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+  if (!dt_ok(src_dtype) || !dt_ok(dst_dtype) || !src || !dst) return VCT_E_ARG;
+  if (n <= 0) return VCT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  if (src_dtype == VCT_F32 && dst_dtype == VCT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == VCT_BF16 && dst_dtype == VCT_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == VCT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, void* stream) {
+  if (!dt_ok(dtype) || !x || !out) return VCT_E_ARG;
+  if (rows <= 0 || cols <= 0) return VCT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out);
+  else
+    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_advance_seed(uint32_t* seed, void* stream) {
+  if (!seed) return VCT_E_ARG;
+  hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_abi_version(void) { return VCT_ABI_VERSION; }
+extern "C" int vct_build_info(char* buf, int buflen) {
+  static const char info[] = "libvct_hip gfx950 (CDNA4) abi 1; bf16 mfma 16x16x32 + f32 mfma 16x16x4";
+  int n = (int)sizeof(info) - 1;
+  if (buf && buflen > 0) {
+    int c = n < buflen - 1 ? n : buflen - 1;
+    for (int i = 0; i < c; i++) buf[i] = info[i];
+    buf[c] = 0;
+  }
+  return n;
+}

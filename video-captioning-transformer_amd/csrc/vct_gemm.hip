@@ -1,0 +1,418 @@
+// MFMA GEMM family for gfx950:  C[M,N] = epilogue(op(A)[M,K] * op(B)[K,N])
+//
+//  * bf16 inputs : v_mfma_f32_16x16x32_bf16, BK = 64.  K-contiguous operands are staged to LDS as
+//    [rows][BK+8] and read as one ds_read_b128 fragment; operands whose contiguous dimension is the
+//    NON-reduced one (A of dW = dY^T X, B of dX = dY W) are staged as [BK][rows+16] and read with the
+//    gfx950 LDS transpose read (ds_read_b64_tr_b16) -- no transposed copies in HBM, no 2-byte LDS
+//    scatter.
+//  * f32 inputs  : v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), BK = 16, the tight-parity mode.
+//  * 256-thread workgroups (4 waves as 2x2), tile 128x128 or 64x64, register prefetch of the next
+//    K tile while the current one is in the matrix pipe, optional split-K with a deterministic
+//    second-pass reduce (weight gradients: tiny outputs, long K = tokens).
+//  * fused epilogues: bias, GELU/ReLU (+ saving the pre-activation), counter-hash dropout,
+//    residual-gradient accumulate, activation-derivative multiply, bias gradient (row sums of op(A)
+//    via one extra MFMA against a ones fragment).
+#include "vct_common.h"
+
+namespace vct {
+
+struct GemmP {
+  const void* A; const void* B; void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int kt_per_split;  // BK tiles per blockIdx.z
+  int tiles_n;
+  int act;        // forward activation applied after bias
+  int dact_kind;  // activation whose derivative multiplies the result (dact != nullptr)
+  const float* bias;
+  void* preact; long ld_preact;
+  const void* addend; long ld_addend;
+  const void* dact; long ld_dact;
+  const uint32_t* seed; uint32_t site; float p_drop;
+  float* bias_grad;
+  float* partial;       // != nullptr: split-K mode, raw accumulators to partial[z][M*N]
+  float* bias_partial;  // split-K mode: [z][M]
+};
+
+template <typename TI> struct GemmCfg;
+template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8, KPAD = 8; };
+template <> struct GemmCfg<float> { static constexpr int BK = 16, VEC = 4, KPAD = 4; };
+
+// one global->register vector (16 bytes) ---------------------------------------------------------
+struct alignas(16) Vec16 { uint32_t w[4]; };
+__device__ __forceinline__ Vec16 vec_zero() { Vec16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u; return v; }
+
+// Operand staging.  KC = stored [rows][K] (K contiguous); MC = stored [K][rows] (rows contiguous).
+// R = rows of the tile (BM or BN).  LDS images:
+//   bf16 KC : [R][BK+8]      bf16 MC : [BK][R+16]  (read by ds_read_b64_tr_b16)
+//   f32  KC : [R][BK+4]      f32  MC : transposed while storing into the same [R][BK+4] image
+template <typename TI, bool MC, int R>
+struct Stager {
+  using Cfg = GemmCfg<TI>;
+  static constexpr int BK = Cfg::BK, VEC = Cfg::VEC;
+  static constexpr bool BF = sizeof(TI) == 2;
+  static constexpr int NV = (R * BK / VEC) / 256;  // vectors per thread
+  static constexpr int KC_STRIDE = BK + Cfg::KPAD;
+  static constexpr int MC_STRIDE = R + 16;
+  static constexpr int LDS_ELEMS = (BF && MC) ? BK * MC_STRIDE : R * KC_STRIDE;
+  static_assert(NV >= 1, "tile too small for 256 threads");
+
+  // r_ext: valid rows; K: valid reduction length; reads along the contiguous dim are predicated per
+  // 16-byte vector (extent rounded up to VEC -- the producer zero-pads / leading dim covers it).
+  __device__ __forceinline__ static void load(Vec16 (&regs)[NV], const TI* __restrict__ base, long ld, int r0,
+                                              int r_ext, int k0, int K) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int v = tid + i * 256;
+      if constexpr (!MC) {
+        constexpr int VPR = BK / VEC;
+        const int row = v / VPR, kc = (v % VPR) * VEC;
+        const int gr = r0 + row, gk = k0 + kc;
+        regs[i] = (gr < r_ext && gk < K) ? *reinterpret_cast<const Vec16*>(base + (long)gr * ld + gk) : vec_zero();
+      } else {
+        constexpr int VPR = R / VEC;
+        const int krow = v / VPR, rc = (v % VPR) * VEC;
+        const int gk = k0 + krow, gr = r0 + rc;
+        regs[i] = (gk < K && gr < r_ext) ? *reinterpret_cast<const Vec16*>(base + (long)gk * ld + gr) : vec_zero();
+      }
+    }
+  }
+  __device__ __forceinline__ static void store(const Vec16 (&regs)[NV], TI* lds) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int v = tid + i * 256;
+      if constexpr (!MC) {
+        constexpr int VPR = BK / VEC;
+        const int row = v / VPR, kc = (v % VPR) * VEC;
+        *reinterpret_cast<Vec16*>(lds + row * KC_STRIDE + kc) = regs[i];
+      } else if constexpr (BF) {
+        constexpr int VPR = R / VEC;
+        const int krow = v / VPR, rc = (v % VPR) * VEC;
+        *reinterpret_cast<Vec16*>(lds + krow * MC_STRIDE + rc) = regs[i];
+      } else {
+        constexpr int VPR = R / VEC;
+        const int krow = v / VPR, rc = (v % VPR) * VEC;
+#pragma unroll
+        for (int j = 0; j < 4; j++) reinterpret_cast<uint32_t*>(lds)[(rc + j) * KC_STRIDE + krow] = regs[i].w[j];
+      }
+    }
+  }
+};
+
+// fragment fetch for one 16-row MFMA tile starting at tile row `r_base` --------------------------
+// bf16: returns the 8 k-values this lane owns for k-step `ks` (32 wide).  KSPLIT selects the k-slot
+// mapping {g*4+j, 16+g*4+j} instead of {g*8+j}; both operands of a TN product use it so the two
+// transpose reads of lanes 0..31 cover 8 consecutive LDS rows (bank-conflict free).
+template <bool MC, int R, bool KSPLIT>
+__device__ __forceinline__ bf16x8 frag_bf16(const bf16_t* lds, int r_base, int ks, int lane) {
+  using S = Stager<bf16_t, MC, R>;
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (!MC) {
+    if constexpr (!KSPLIT) {
+      return *reinterpret_cast<const bf16x8*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + g * 8);
+    } else {
+      const s16x4 lo = *reinterpret_cast<const s16x4*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + g * 4);
+      const s16x4 hi = *reinterpret_cast<const s16x4*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + 16 + g * 4);
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  } else {
+    const int kb1 = ks * 32 + (KSPLIT ? g * 4 : g * 8);
+    const int kb2 = KSPLIT ? ks * 32 + 16 + g * 4 : kb1 + 4;
+    const int col = r_base + (i & 3) * 4;
+    const s16x4 lo = lds_tr16(lds + (kb1 + (i >> 2)) * S::MC_STRIDE + col);
+    const s16x4 hi = lds_tr16(lds + (kb2 + (i >> 2)) * S::MC_STRIDE + col);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <typename TI, typename TO, int TA, int TB, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  using Cfg = GemmCfg<TI>;
+  constexpr bool BF = sizeof(TI) == 2;
+  constexpr int BK = Cfg::BK;
+  constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
+  constexpr bool KSPLIT = BF && A_MC && B_MC;
+  using SA = Stager<TI, A_MC, BM>;
+  using SB = Stager<TI, B_MC, BN>;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+
+  __shared__ __attribute__((aligned(16))) TI lds_a[SA::LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) TI lds_b[SB::LDS_ELEMS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * p.kt_per_split;
+  const int kt_end = min(nkt, kt_begin + p.kt_per_split);
+
+  const TI* A = reinterpret_cast<const TI*>(p.A);
+  const TI* B = reinterpret_cast<const TI*>(p.B);
+
+  f32x4 acc[TM][TN];
+  f32x4 accb[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+  }
+  const bool do_bias_grad = (p.bias_grad != nullptr) && (tile_n == 0) && (wn == 0);
+
+  Vec16 ra[SA::NV], rb[SB::NV];
+  if (kt_begin < kt_end) {
+    SA::load(ra, A, p.lda, m0, p.M, kt_begin * BK, p.K);
+    SB::load(rb, B, p.ldb, n0, p.N, kt_begin * BK, p.K);
+  }
+  for (int kt = kt_begin; kt < kt_end; kt++) {
+    __syncthreads();  // previous tile's fragment reads are done
+    SA::store(ra, lds_a);
+    SB::store(rb, lds_b);
+    __syncthreads();
+    if (kt + 1 < kt_end) {  // next tile's global loads fly under the MFMAs below
+      SA::load(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K);
+      SB::load(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K);
+    }
+    if constexpr (BF) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ks++) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[i] = frag_bf16<A_MC, BM, KSPLIT>(lds_a, wm * WM + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[j] = frag_bf16<B_MC, BN, KSPLIT>(lds_b, wn * WN + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_bias_grad) {
+          const s16x8 o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+          const bf16x8 ones = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+          for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* la = reinterpret_cast<const float*>(lds_a);
+      const float* lb = reinterpret_cast<const float*>(lds_b);
+      const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; kk++) {
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[i] = la[(wm * WM + i * 16 + i16) * SA::KC_STRIDE + kk * 4 + g];
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[j] = lb[(wn * WN + j * 16 + i16) * SB::KC_STRIDE + kk * 4 + g];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_bias_grad) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], 1.0f, accb[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r -------------
+  const int c16 = lane & 15, g4 = (lane >> 4) * 4;
+  if (p.partial != nullptr) {
+    float* part = p.partial + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = m0 + wm * WM + i * 16 + g4 + r, col = n0 + wn * WN + j * 16 + c16;
+          if (row < p.M && col < p.N) part[(size_t)row * p.N + col] = acc[i][j][r];
+        }
+    if (do_bias_grad && c16 == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = m0 + wm * WM + i * 16 + g4 + r;
+          if (row < p.M) p.bias_partial[(size_t)blockIdx.z * p.M + row] = accb[i][r];
+        }
+    }
+    return;
+  }
+  const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
+  TO* C = reinterpret_cast<TO*>(p.C);
+  TO* preact = reinterpret_cast<TO*>(p.preact);
+  const TO* addend = reinterpret_cast<const TO*>(p.addend);
+  const TO* dact = reinterpret_cast<const TO*>(p.dact);
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + wn * WN + j * 16 + c16;
+      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * WM + i * 16 + g4 + r;
+        if (row < p.M && col < p.N) {
+          float v = acc[i][j][r] + bv;
+          if (preact != nullptr) preact[(size_t)row * p.ld_preact + col] = from_f<TO>(v);
+          v = act_f(p.act, v);
+          if (dact != nullptr) v *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col]));
+          v *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
+          if (addend != nullptr) v += to_f<TO>(addend[(size_t)row * p.ld_addend + col]);
+          C[(size_t)row * p.ldc + col] = from_f<TO>(v);
+        }
+      }
+    }
+  if (do_bias_grad && c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * WM + i * 16 + g4 + r;
+        if (row < p.M) p.bias_grad[row] = accb[i][r];
+      }
+  }
+}
+
+// deterministic split-K second pass: C[i] = sum_z partial[z][i] (fixed z order)
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, TO* __restrict__ C, long ldc, int M, int N,
+                                     int S, const float* __restrict__ bias_partial, float* __restrict__ bias_grad) {
+  const size_t total = (size_t)M * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int z = 0; z < S; z++) s += partial[(size_t)z * total + idx];
+    const int row = (int)(idx / N), col = (int)(idx % N);
+    C[(size_t)row * ldc + col] = from_f<TO>(s);
+  }
+  if (bias_grad != nullptr) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < M; row += gridDim.x * blockDim.x) {
+      float s = 0.0f;
+      for (int z = 0; z < S; z++) s += bias_partial[(size_t)z * M + row];
+      bias_grad[row] = s;
+    }
+  }
+}
+
+struct Plan { int bm; int split; int tiles_m, tiles_n, nkt, kt_per; };
+
+static bool gemm_can_split(const vct_gemm_desc* d) {
+  return d->out_dtype == VCT_F32 && d->bias == nullptr && d->act == VCT_ACT_NONE && d->preact == nullptr &&
+         d->addend == nullptr && d->dact_src == nullptr && !(d->seed != nullptr && d->p_drop > 0.0f);
+}
+
+static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
+  Plan pl;
+  const int BK = d->dtype == VCT_BF16 ? 64 : 16;
+  pl.nkt = (d->K + BK - 1) / BK;
+  const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+  pl.bm = (t128 >= 384) ? 128 : 64;
+  pl.tiles_m = (d->M + pl.bm - 1) / pl.bm;
+  pl.tiles_n = (d->N + pl.bm - 1) / pl.bm;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  int split = 1;
+  if (d->split_k > 1) split = d->split_k;
+  else if (d->split_k == 0 && tiles < 256 && pl.nkt >= 8) split = (int)((511 + tiles) / tiles);
+  if (!gemm_can_split(d) || !have_ws) split = 1;
+  if (split > pl.nkt / 2) split = pl.nkt / 2 > 0 ? pl.nkt / 2 : 1;
+  if (split < 1) split = 1;
+  pl.kt_per = (pl.nkt + split - 1) / split;
+  pl.split = (pl.nkt + pl.kt_per - 1) / pl.kt_per;
+  return pl;
+}
+
+template <typename TI, typename TO, int TA, int TB, int BM>
+static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_kernel<TI, TO, TA, TB, BM, BM>), grid, dim3(256), 0, st, p);
+}
+
+template <typename TI, typename TO>
+static int dispatch_layout(const vct_gemm_desc* d, const GemmP& p, int bm, dim3 grid, hipStream_t st) {
+  const int key = d->ta * 2 + d->tb;
+#define VCT_L(TA_, TB_)                                              \
+  if (bm == 128) launch_gemm<TI, TO, TA_, TB_, 128>(p, grid, st);    \
+  else launch_gemm<TI, TO, TA_, TB_, 64>(p, grid, st);               \
+  return VCT_OK;
+  switch (key) {
+    case 1: { VCT_L(0, 1) }  // NT: x W^T
+    case 0: { VCT_L(0, 0) }  // NN: dY W
+    case 2: { VCT_L(1, 0) }  // TN: dY^T X
+    default: return VCT_E_SHAPE;
+  }
+#undef VCT_L
+}
+
+}  // namespace vct
+
+using namespace vct;
+
+extern "C" int64_t vct_gemm_workspace_bytes(const vct_gemm_desc* d) {
+  if (d == nullptr) return 0;
+  const Plan pl = gemm_plan(d, true);
+  if (pl.split <= 1) return 0;
+  return (int64_t)pl.split * ((int64_t)d->M * d->N + d->M) * 4;
+}
+
+extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
+  if (d == nullptr || d->A == nullptr || d->B == nullptr || d->C == nullptr) return VCT_E_ARG;
+  if (d->dtype != VCT_F32 && d->dtype != VCT_BF16) return VCT_E_ARG;
+  if (d->out_dtype != VCT_F32 && d->out_dtype != VCT_BF16) return VCT_E_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return VCT_E_SHAPE;
+  if (d->ta == 1 && d->tb == 1) return VCT_E_SHAPE;
+  const int vec = d->dtype == VCT_BF16 ? 8 : 4;
+  if (d->lda % vec || d->ldb % vec) return VCT_E_ALIGN;
+  if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return VCT_E_ALIGN;
+  if (d->dact_src != nullptr && d->act == VCT_ACT_NONE) return VCT_E_ARG;  // dact needs the activation kind
+  hipStream_t st = (hipStream_t)stream;
+
+  const int64_t need = vct_gemm_workspace_bytes(d);
+  const bool have_ws = d->workspace != nullptr && d->workspace_bytes >= need && need > 0;
+  if (d->split_k > 1 && !have_ws) return VCT_E_WORKSPACE;
+  const Plan pl = gemm_plan(d, have_ws);
+
+  GemmP p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.kt_per_split = pl.kt_per;
+  p.tiles_n = pl.tiles_n;
+  p.act = d->dact_src != nullptr ? VCT_ACT_NONE : d->act;
+  p.dact_kind = d->dact_src != nullptr ? d->act : VCT_ACT_NONE;
+  p.bias = d->bias;
+  p.preact = d->preact; p.ld_preact = d->ld_preact;
+  p.addend = d->addend; p.ld_addend = d->ld_addend;
+  p.dact = d->dact_src; p.ld_dact = d->ld_dact;
+  p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
+  p.bias_grad = d->bias_grad;
+  p.partial = nullptr; p.bias_partial = nullptr;
+  if (pl.split > 1) {
+    p.partial = reinterpret_cast<float*>(d->workspace);
+    p.bias_partial = p.partial + (size_t)pl.split * d->M * d->N;
+  }
+  const dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  int rc;
+  if (d->dtype == VCT_BF16) {
+    rc = d->out_dtype == VCT_BF16 ? dispatch_layout<bf16_t, bf16_t>(d, p, pl.bm, grid, st)
+                                  : dispatch_layout<bf16_t, float>(d, p, pl.bm, grid, st);
+  } else {
+    if (d->out_dtype != VCT_F32) return VCT_E_ARG;
+    rc = dispatch_layout<float, float>(d, p, pl.bm, grid, st);
+  }
+  if (rc != VCT_OK) return rc;
+  VCT_CHECK_LAUNCH();
+  if (pl.split > 1) {
+    const size_t total = (size_t)d->M * d->N;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p.partial,
+                       reinterpret_cast<float*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
+    VCT_CHECK_LAUNCH();
+  }
+  return VCT_OK;
+}

@@ -1,0 +1,228 @@
+// y = LayerNorm(res + dropout(x)) forward / backward for gfx950.  HBM-bound: one wave per row, the
+// row lives in registers (16-byte loads, <= 16 values per lane => d <= 1024), statistics by wave
+// shuffles, two-pass variance in fp32.  The backward recomputes the pre-norm sum from (x, res) and
+// the dropout mask from its counter hash, writes ds (and the dropout-masked copy that feeds the
+// producing GEMM's backward), and accumulates dgamma/dbeta as per-wave column partials that a
+// second tiny kernel sums in a fixed order (deterministic, no float atomics).
+#include "vct_common.h"
+
+namespace vct {
+
+constexpr int LN_ROWS_PER_WAVE = 8;
+
+template <typename T> struct LnCfg;
+template <> struct LnCfg<float> { static constexpr int VEC = 4, MAXIT = 4; };
+template <> struct LnCfg<bf16_t> { static constexpr int VEC = 8, MAXIT = 2; };
+
+template <typename T, int VEC> struct alignas(16) RowVec { T v[VEC]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ y, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, const uint32_t* seed, uint32_t site,
+                                                         float p_drop) {
+  constexpr int VEC = LnCfg<T>::VEC, MAXIT = LnCfg<T>::MAXIT;
+  using RV = RowVec<T, VEC>;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const Dropout dr = make_dropout(seed, site, p_drop);
+  const int nvec = d / VEC;
+  float s[MAXIT][VEC];
+  float sum = 0.0f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int vi = it * 64 + lane;
+    if (vi < nvec) {
+      const RV xv = *reinterpret_cast<const RV*>(x + (size_t)row * d + vi * VEC);
+      RV rv;
+      if (res != nullptr) rv = *reinterpret_cast<const RV*>(res + (size_t)row * d + vi * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        float v = to_f<T>(xv.v[j]) * drop_mult(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC + j));
+        if (res != nullptr) v += to_f<T>(rv.v[j]);
+        s[it][j] = v;
+        sum += v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) s[it][j] = 0.0f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float sq = 0.0f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int vi = it * 64 + lane;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { const float c = s[it][j] - mean; sq += c * c; }
+    }
+  }
+  const float var = wave_sum(sq) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int vi = it * 64 + lane;
+    if (vi < nvec) {
+      RV out;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const int c = vi * VEC + j;
+        out.v[j] = from_f<T>((s[it][j] - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<RV*>(y + (size_t)row * d + vi * VEC) = out;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ res, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         T* __restrict__ ds, T* __restrict__ dxo, float* __restrict__ param_ws,
+                                                         const uint32_t* seed, uint32_t site, float p_drop) {
+  constexpr int VEC = LnCfg<T>::VEC, MAXIT = LnCfg<T>::MAXIT;
+  using RV = RowVec<T, VEC>;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave = partial row in param_ws
+  const Dropout dr = make_dropout(seed, site, p_drop);
+  const int nvec = d / VEC;
+  float pg[MAXIT][VEC], pb[MAXIT][VEC], g[MAXIT][VEC];
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int vi = it * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      pg[it][j] = 0.0f; pb[it][j] = 0.0f;
+      g[it][j] = (vi < nvec) ? gamma[vi * VEC + j] : 0.0f;
+    }
+  }
+  for (int rr = 0; rr < LN_ROWS_PER_WAVE; rr++) {
+    const int row = gw * LN_ROWS_PER_WAVE + rr;
+    if (row >= M) break;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[MAXIT][VEC], dxh[MAXIT][VEC], dm[MAXIT][VEC];
+    float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec) {
+        const RV xv = *reinterpret_cast<const RV*>(x + (size_t)row * d + vi * VEC);
+        const RV dv = *reinterpret_cast<const RV*>(dy + (size_t)row * d + vi * VEC);
+        RV rv;
+        if (res != nullptr) rv = *reinterpret_cast<const RV*>(res + (size_t)row * d + vi * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const float m = drop_mult(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC + j));
+          float s = to_f<T>(xv.v[j]) * m;
+          if (res != nullptr) s += to_f<T>(rv.v[j]);
+          const float h = (s - mean) * rstd;
+          const float dyv = to_f<T>(dv.v[j]);
+          const float dh = dyv * g[it][j];
+          xh[it][j] = h; dxh[it][j] = dh; dm[it][j] = m;
+          c1 += dh; c2 += dh * h;
+          pg[it][j] += dyv * h; pb[it][j] += dyv;
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)d;
+    c2 = wave_sum(c2) / (float)d;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec) {
+        RV o1, o2;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const float v = rstd * (dxh[it][j] - c1 - xh[it][j] * c2);
+          o1.v[j] = from_f<T>(v);
+          o2.v[j] = from_f<T>(v * dm[it][j]);
+        }
+        *reinterpret_cast<RV*>(ds + (size_t)row * d + vi * VEC) = o1;
+        if (dxo != nullptr && dxo != ds) *reinterpret_cast<RV*>(dxo + (size_t)row * d + vi * VEC) = o2;
+      }
+    }
+  }
+  // column partials of this wave -> param_ws[gw][0][d] (dgamma), [gw][1][d] (dbeta)
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int vi = it * 64 + lane;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        param_ws[((size_t)gw * 2 + 0) * d + vi * VEC + j] = pg[it][j];
+        param_ws[((size_t)gw * 2 + 1) * d + vi * VEC + j] = pb[it][j];
+      }
+    }
+  }
+}
+
+__global__ void ln_param_finalize_kernel(int nws, int d, const float* __restrict__ ws, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * d) return;
+  const int which = c / d, col = c % d;
+  float s = 0.0f;
+  for (int r = 0; r < nws; r++) s += ws[((size_t)r * 2 + which) * d + col];
+  (which == 0 ? dgamma : dbeta)[col] = s;
+}
+
+}  // namespace vct
+using namespace vct;
+
+extern "C" int vct_ln_ws_rows(int M) {
+  const int waves = (M + LN_ROWS_PER_WAVE - 1) / LN_ROWS_PER_WAVE;
+  return ((waves + 3) / 4) * 4;
+}
+
+static int ln_check(int dtype, int M, int d) {
+  if (dtype != VCT_F32 && dtype != VCT_BF16) return VCT_E_ARG;
+  if (M <= 0 || d <= 0) return VCT_E_SHAPE;
+  const int vec = dtype == VCT_BF16 ? 8 : 4;
+  if (d % vec) return VCT_E_ALIGN;
+  if (d > 1024) return VCT_E_SHAPE;
+  return VCT_OK;
+}
+
+extern "C" int vct_add_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma,
+                              const float* beta, void* y, float* mean, float* rstd, const uint32_t* seed,
+                              uint32_t site, float p_drop, void* stream) {
+  int rc = ln_check(dtype, M, d);
+  if (rc) return rc;
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return VCT_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + 3) / 4);
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)x, (const bf16_t*)res,
+                       gamma, beta, (bf16_t*)y, mean, rstd, seed, site, p_drop);
+  else
+    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)x, (const float*)res,
+                       gamma, beta, (float*)y, mean, rstd, seed, site, p_drop);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,
+                              const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
+                              float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
+                              float p_drop, void* stream) {
+  int rc = ln_check(dtype, M, d);
+  if (rc) return rc;
+  if (!dy || !x || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta || !param_ws) return VCT_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nws = vct_ln_ws_rows(M);
+  const dim3 grid(nws / 4);
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop);
+  else
+    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
+                       (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop);
+  VCT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}

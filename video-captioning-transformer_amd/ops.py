@@ -1,0 +1,176 @@
+"""Tensor-level wrappers over the C ABI (include/vct_hip.h).  PyTorch supplies device memory and the
+current HIP stream; every function here enqueues hand-written gfx950 kernels and nothing else."""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Drop = Optional[Tuple[torch.Tensor, int, float]]  # (seed tensor uint32[1] on device, site id, p)
+
+
+def _drop(d: Drop):
+    if d is None or d[2] <= 0.0:
+        return 0, 0, 0.0
+    return d[0].data_ptr(), int(d[1]), float(d[2])
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view required"
+    return t.stride(0)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = False, tb: bool = True,
+         bias: Optional[torch.Tensor] = None, act: Optional[str] = None, preact: Optional[torch.Tensor] = None,
+         addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
+         bias_grad: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, split_k: int = 0,
+         n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
+    tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
+    logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns)."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.dtype, d.out_dtype = L.dtype_code(a.dtype), L.dtype_code(out.dtype)
+    assert b.dtype == a.dtype
+    d.ta, d.tb = int(ta), int(tb)
+    M = a.shape[1] if ta else a.shape[0]
+    K = a.shape[0] if ta else a.shape[1]
+    N = b.shape[0] if tb else b.shape[1]
+    Kb = b.shape[1] if tb else b.shape[0]
+    if k_valid is not None:
+        K = k_valid
+    else:
+        assert K == Kb, (a.shape, b.shape, ta, tb)
+    if n_valid is not None:
+        N = n_valid
+    if m_valid is not None:
+        M = m_valid
+    d.M, d.N, d.K = M, N, K
+    d.act = L.ACT[act]
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), out.data_ptr(), _ld(out)
+    d.bias = L.ptr(bias)
+    if preact is not None:
+        d.preact, d.ld_preact = preact.data_ptr(), _ld(preact)
+    if addend is not None:
+        d.addend, d.ld_addend = addend.data_ptr(), _ld(addend)
+    if dact_src is not None:
+        d.dact_src, d.ld_dact = dact_src.data_ptr(), _ld(dact_src)
+    d.seed, d.site, d.p_drop = _drop(dropout)
+    d.bias_grad = L.ptr(bias_grad)
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    d.split_k = split_k
+    L.check(lib.vct_gemm(d, L.stream_ptr()), "vct_gemm")
+    return out
+
+
+def gemm_workspace_bytes(M: int, N: int, K: int, dtype: torch.dtype) -> int:
+    """Upper bound of the split-K workspace the weight-gradient GEMM [M,N] (reduction K) may use."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.dtype, d.out_dtype, d.ta, d.tb, d.M, d.N, d.K = L.dtype_code(dtype), L.F32, 1, 0, M, N, K
+    return int(lib.vct_gemm_workspace_bytes(d))
+
+
+def _attn_desc(dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout):
+    d = L.AttnDesc()
+    d.dtype, d.B, d.H, d.Lq, d.Lk, d.hd, d.causal = L.dtype_code(dtype), B, H, Lq, Lk, hd, int(causal)
+    d.q, d.ldq, d.k, d.ldk, d.v, d.ldv = q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v)
+    d.key_pad = L.ptr(key_pad)
+    d.seed, d.site, d.p_drop = _drop(dropout)
+    return d
+
+
+def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
+    """q:[B*Lq, >=H*hd] views (any row stride), k,v:[B*Lk, ..]; o:[B*Lq, H*hd].  key_pad: uint8 [B,Lk]."""
+    hd = o.shape[1] // H
+    d = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
+    d.o, d.ldo = o.data_ptr(), _ld(o)
+    L.check(L.load().vct_attn_fwd(d, L.stream_ptr()), "vct_attn_fwd")
+    return o
+
+
+def attn_bwd(q, k, v, d_o, dq, dk, dv, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
+    hd = d_o.shape[1] // H
+    d = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
+    d.d_o, d.ld_do = d_o.data_ptr(), _ld(d_o)
+    d.dq, d.ld_dq, d.dk, d.ld_dk, d.dv, d.ld_dv = dq.data_ptr(), _ld(dq), dk.data_ptr(), _ld(dk), dv.data_ptr(), _ld(dv)
+    L.check(L.load().vct_attn_bwd(d, L.stream_ptr()), "vct_attn_bwd")
+
+
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, dropout: Drop = None):
+    M, dm = x.shape
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_add_ln_fwd(L.dtype_code(x.dtype), M, dm, x.data_ptr(), L.ptr(res), gamma.data_ptr(),
+                                    beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), s, site, p,
+                                    L.stream_ptr()), "vct_add_ln_fwd")
+    return y
+
+
+def ln_ws_rows(M: int) -> int:
+    return int(L.load().vct_ln_ws_rows(M))
+
+
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, ds, dxo, dgamma, dbeta, param_ws, dropout: Drop = None):
+    M, dm = x.shape
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_add_ln_bwd(L.dtype_code(x.dtype), M, dm, dy.data_ptr(), x.data_ptr(), L.ptr(res),
+                                    gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ds.data_ptr(), L.ptr(dxo),
+                                    dgamma.data_ptr(), dbeta.data_ptr(), param_ws.data_ptr(), s, site, p,
+                                    L.stream_ptr()), "vct_add_ln_bwd")
+
+
+def enc_frontend_fwd(u, pe_rows, z, B, T):
+    L.check(L.load().vct_enc_frontend_fwd(L.dtype_code(u.dtype), B, T, u.shape[1], u.data_ptr(), pe_rows.data_ptr(),
+                                          z.data_ptr(), L.stream_ptr()), "vct_enc_frontend_fwd")
+    return z
+
+
+def enc_frontend_bwd(dz, du, B, T):
+    L.check(L.load().vct_enc_frontend_bwd(L.dtype_code(dz.dtype), B, T, dz.shape[1], dz.data_ptr(), du.data_ptr(),
+                                          L.stream_ptr()), "vct_enc_frontend_bwd")
+    return du
+
+
+def embed_fwd(ids, S, table, pos, x, dropout: Drop = None):
+    """ids: int64 [B, S_total] (row stride = ids.stride(0)); uses the first S columns of each row."""
+    B = ids.shape[0]
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_embed_fwd(L.dtype_code(x.dtype), B, S, x.shape[1], ids.data_ptr(), ids.stride(0),
+                                   table.data_ptr(), pos.data_ptr(), x.data_ptr(), s, site, p, L.stream_ptr()),
+            "vct_embed_fwd")
+    return x
+
+
+def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None):
+    B = ids.shape[0]
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_embed_bwd(L.dtype_code(dx.dtype), B, S, dx.shape[1], dtable.shape[0], ids.data_ptr(),
+                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), s, site, p,
+                                   L.stream_ptr()), "vct_embed_bwd")
+
+
+def sce_loss(logits, V, labels, S, pad_id, alpha, loss_out, dlogits, row_ws):
+    """logits [N, ld>=V]; labels: int64 2-D view [B, >=S] whose first S columns are the targets."""
+    N = logits.shape[0]
+    L.check(L.load().vct_sce_loss(L.dtype_code(logits.dtype), N, S, V, logits.data_ptr(), _ld(logits), labels.data_ptr(),
+                                  labels.stride(0), int(pad_id), float(alpha), loss_out.data_ptr(), L.ptr(dlogits),
+                                  _ld(dlogits) if dlogits is not None else 0, row_ws.data_ptr(), L.stream_ptr()),
+            "vct_sce_loss")
+    return loss_out
+
+
+def cast(src, dst):
+    L.check(L.load().vct_cast(L.dtype_code(src.dtype), L.dtype_code(dst.dtype), src.data_ptr(), dst.data_ptr(),
+                              src.numel(), L.stream_ptr()), "vct_cast")
+    return dst
+
+
+def argmax_rows(x, out, cols=None):
+    L.check(L.load().vct_argmax_rows(L.dtype_code(x.dtype), x.shape[0], cols or x.shape[1], x.data_ptr(), _ld(x),
+                                     out.data_ptr(), L.stream_ptr()), "vct_argmax_rows")
+    return out
+
+
+def advance_seed(seed):
+    L.check(L.load().vct_advance_seed(seed.data_ptr(), L.stream_ptr()), "vct_advance_seed")
