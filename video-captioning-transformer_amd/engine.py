@@ -1,0 +1,393 @@
+"""Forward / backward schedules of the caption path over the gfx950 kernels.
+
+The reference runs this path as ~60 stock torch.nn calls under autograd (model/MMEncoder.py:244-276,
+model/CapDecoder.py:34-60, torch nn/modules/transformer.py:951-982,1143-1199).  Here the graph is
+static and known, so forward and backward are explicit kernel schedules over pre-allocated HBM
+buffers: no autograd tape, no temporaries, no host synchronisation -- the whole step is
+hipGraph-capturable.  Every arithmetic step is a libvct_hip.so kernel (ops.py); torch is used for
+memory, streams and a few boolean mask preparations only.
+
+Data layout in HBM (row-major, tokens x features):
+  encoder tokens   Me = B*(T+1) rows, decoder tokens Md = B*(S-1) rows, d columns
+  packed projections qkv [M,3d], cross kv [Me,2d]; FFN hidden [M,ff]; logits [Md, Vp] with
+  Vp = V rounded up to 32 and zero-padded columns; statistics (mean, rstd) fp32 [M].
+  Activations are bf16 (throughput mode) or fp32 (parity mode); parameters stay fp32 masters with a
+  bf16 shadow refreshed once per step; every parameter gradient is fp32.
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+ENC_SITE, DEC_SITE, EMB_SITE = 0, 1000, 999
+
+
+class ParamSet:
+    """fp32 master parameters (views of one flat buffer), their fp32 gradient views and the
+    compute-dtype shadow used by the GEMMs.  Order = gradient-ready order of the backward pass so
+    that contiguous slices of the flat gradient buffer are the all-reduce buckets."""
+
+    ALIGN = 64  # elements; keeps every view 16-byte aligned in fp32 and bf16
+
+    def __init__(self, named: List, device, compute_dtype: torch.dtype, no_shadow=()):
+        self.names = [n for n, _ in named]
+        self.params = {n: p for n, p in named}
+        self.device, self.compute_dtype = device, compute_dtype
+        self.offsets, off = {}, 0
+        for n, p in named:
+            self.offsets[n] = off
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.gflat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.no_shadow = set(no_shadow)
+        for n, p in named:
+            o, k = self.offsets[n], p.numel()
+            view = self.flat[o:o + k].view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+        self.g = {n: self.gflat[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape) for n, p in named}
+        if compute_dtype == torch.float32:
+            self.cflat = self.flat
+            self.c = {n: p.data for n, p in named}
+        else:
+            self.cflat = torch.zeros(self.total, dtype=compute_dtype, device=device)
+            self.c = {n: self.cflat[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape) for n, p in named}
+        self._stamp = None
+        # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
+        self.cast_ranges, start = [], 0
+        for n in self.names:
+            if n in self.no_shadow:
+                if self.offsets[n] > start:
+                    self.cast_ranges.append((start, self.offsets[n]))
+                start = self.offsets[n] + (self.params[n].numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if start < self.total:
+            self.cast_ranges.append((start, self.total))
+
+    def intact(self) -> bool:
+        """True while every nn.Parameter still aliases the flat buffer (Module.to() would break it)."""
+        base = self.flat.data_ptr()
+        for n in (self.names[0], self.names[-1]):
+            if self.params[n].data_ptr() != base + 4 * self.offsets[n]:
+                return False
+        return True
+
+    def refresh_shadow(self, force=False):
+        """bf16 shadow <- fp32 masters (one cast kernel per contiguous range)."""
+        if self.compute_dtype == torch.float32:
+            return
+        stamp = None
+        if not force:
+            stamp = sum(p._version for p in self.params.values())
+            if stamp == self._stamp:
+                return
+        for a, b in self.cast_ranges:
+            ops.cast(self.flat[a:b], self.cflat[a:b])
+        self._stamp = stamp if stamp is not None else sum(p._version for p in self.params.values())
+
+    def install_grads(self):
+        for n, p in self.params.items():
+            if p.requires_grad and p.grad is not self.g[n]:
+                if p.grad is not None and p.grad.data_ptr() != self.g[n].data_ptr():
+                    self.g[n].add_(p.grad)  # honour a pre-existing accumulated gradient
+                p.grad = self.g[n]
+
+
+class _Buf:
+    """Named, lazily allocated device buffers of one shape configuration (static addresses)."""
+
+    def __init__(self, device):
+        self.device, self.t = device, {}
+
+    def get(self, name, shape, dtype):
+        t = self.t.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.t[name] = t
+        return t
+
+
+class _StackBase:
+    def __init__(self, ps: ParamSet, prefix: str, cfg: dict, seed: torch.Tensor):
+        self.ps, self.pre, self.cfg, self.seed = ps, prefix, cfg, seed
+        self.dev, self.dt = ps.device, ps.compute_dtype
+        self.bufs: Dict[tuple, _Buf] = {}
+        self.p_drop = 0.0
+        self._ws = None
+
+    # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
+    def W(self, k): return self.ps.c[self.pre + k]
+    def F(self, k): return self.ps.params[self.pre + k].data
+    def G(self, k): return self.ps.g[self.pre + k]
+
+    def drop(self, site):
+        return (self.seed, site, self.p_drop) if self.p_drop > 0.0 else None
+
+    def gemm_ws(self):
+        if self._ws is None:
+            self._ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.dev)
+        return self._ws
+
+    def buf(self, key) -> _Buf:
+        b = self.bufs.get(key)
+        if b is None:
+            if len(self.bufs) > 4:
+                self.bufs.clear()
+            b = self.bufs[key] = _Buf(self.dev)
+        return b
+
+    # ---- shared sub-blocks -------------------------------------------------------------------
+    def _attn_block_fwd(self, b, tag, lp, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn=True):
+        """x:[Mq,d] queries source; kv_src:[Mk,d].  Returns (a = out_proj(attn) [Mq,d])."""
+        d, H = self.cfg["d"], self.cfg["nhead"]
+        Mq, Mk = x.shape[0], kv_src.shape[0]
+        if self_attn:
+            qkv = b.get(tag + "qkv", (Mq, 3 * d), self.dt)
+            ops.gemm(x, self.W(lp + "in_proj_weight"), qkv, bias=self.F(lp + "in_proj_bias"))
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            q = b.get(tag + "q", (Mq, d), self.dt)
+            kv = b.get(tag + "kv", (Mk, 2 * d), self.dt)
+            ops.gemm(x, self.W(lp + "in_proj_weight")[:d], q, bias=self.F(lp + "in_proj_bias")[:d])
+            ops.gemm(kv_src, self.W(lp + "in_proj_weight")[d:], kv, bias=self.F(lp + "in_proj_bias")[d:])
+            k, v = kv[:, :d], kv[:, d:]
+        o = b.get(tag + "o", (Mq, d), self.dt)
+        ops.attn_fwd(q, k, v, o, Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=self.drop(site))
+        a = b.get(tag + "a", (Mq, d), self.dt)
+        ops.gemm(o, self.W(lp + "out_proj.weight"), a, bias=self.F(lp + "out_proj.bias"))
+        return a
+
+    def _attn_block_bwd(self, b, tag, lp, da, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn, ds_res,
+                        dkv_out=None, dkv_accumulate=False):
+        """da: grad of out_proj output (dropout-masked).  Returns dx = grad wrt x (+ ds_res)."""
+        d, H = self.cfg["d"], self.cfg["nhead"]
+        Mq, Mk = x.shape[0], kv_src.shape[0]
+        ws = self.gemm_ws()
+        o = b.t[tag + "o"]
+        d_o = b.get(tag + "d_o", (Mq, d), self.dt)
+        ops.gemm(da, self.W(lp + "out_proj.weight"), d_o, ta=False, tb=False)
+        ops.gemm(da, o, self.G(lp + "out_proj.weight"), ta=True, tb=False, bias_grad=self.G(lp + "out_proj.bias"), workspace=ws)
+        dx = b.get(tag + "dx", (Mq, d), self.dt)
+        if self_attn:
+            qkv = b.t[tag + "qkv"]
+            dqkv = b.get(tag + "dqkv", (Mq, 3 * d), self.dt)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], d_o, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                         Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=self.drop(site))
+            ops.gemm(dqkv, self.W(lp + "in_proj_weight"), dx, ta=False, tb=False, addend=ds_res)
+            ops.gemm(dqkv, x, self.G(lp + "in_proj_weight"), ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias"), workspace=ws)
+        else:
+            q, kv = b.t[tag + "q"], b.t[tag + "kv"]
+            dq = b.get(tag + "dq", (Mq, d), self.dt)
+            dkv = b.get(tag + "dkv", (Mk, 2 * d), self.dt)
+            ops.attn_bwd(q, kv[:, :d], kv[:, d:], d_o, dq, dkv[:, :d], dkv[:, d:], Bn, H, Lq, Lk, causal=causal,
+                         key_pad=key_pad, dropout=self.drop(site))
+            ops.gemm(dq, self.W(lp + "in_proj_weight")[:d], dx, ta=False, tb=False, addend=ds_res)
+            ops.gemm(dq, x, self.G(lp + "in_proj_weight")[:d], ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias")[:d], workspace=ws)
+            ops.gemm(dkv, self.W(lp + "in_proj_weight")[d:], dkv_out, ta=False, tb=False,
+                     addend=dkv_out if dkv_accumulate else None)
+            ops.gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:], ta=True, tb=False,
+                     bias_grad=self.G(lp + "in_proj_bias")[d:], workspace=ws)
+        return dx
+
+    def _ln_fwd(self, b, tag, np_, x, res, site):
+        M, d = x.shape
+        y = b.get(tag + "y", (M, d), self.dt)
+        ops.add_ln_fwd(x, res, self.F(np_ + "weight"), self.F(np_ + "bias"), y, b.get(tag + "mean", (M,), torch.float32),
+                       b.get(tag + "rstd", (M,), torch.float32), dropout=self.drop(site) if site is not None else None)
+        return y
+
+    def _ln_bwd(self, b, tag, np_, dy, x, res, site):
+        """Returns (ds, dxo): gradient of the pre-norm sum and its dropout-masked copy."""
+        M, d = x.shape
+        ds = b.get(tag + "ds", (M, d), self.dt)
+        drop = self.drop(site) if site is not None else None
+        dxo = b.get(tag + "dxo", (M, d), self.dt) if drop is not None else ds
+        ops.add_ln_bwd(dy, x, res, self.F(np_ + "weight"), b.t[tag + "mean"], b.t[tag + "rstd"], ds, dxo,
+                       self.G(np_ + "weight"), self.G(np_ + "bias"),
+                       b.get("ln_ws", (2 * ops.ln_ws_rows(M) * d,), torch.float32), dropout=drop)
+        return ds, dxo
+
+    def _ffn_fwd(self, b, tag, lp, x, site):
+        M, d = x.shape
+        ff = self.cfg["ff"]
+        hpre = b.get(tag + "hpre", (M, ff), self.dt)
+        h = b.get(tag + "h", (M, ff), self.dt)
+        ops.gemm(x, self.W(lp + "linear1.weight"), h, bias=self.F(lp + "linear1.bias"), act=self.cfg["activation"],
+                 preact=hpre, dropout=self.drop(site))
+        f = b.get(tag + "f", (M, d), self.dt)
+        ops.gemm(h, self.W(lp + "linear2.weight"), f, bias=self.F(lp + "linear2.bias"))
+        return f
+
+    def _ffn_bwd(self, b, tag, lp, df, x, site, ds_res):
+        """df: grad wrt f (dropout-masked).  Returns grad wrt x (+ ds_res)."""
+        M, d = x.shape
+        ff = self.cfg["ff"]
+        ws = self.gemm_ws()
+        dhpre = b.get(tag + "dhpre", (M, ff), self.dt)
+        ops.gemm(df, self.W(lp + "linear2.weight"), dhpre, ta=False, tb=False, act=self.cfg["activation"],
+                 dact_src=b.t[tag + "hpre"], dropout=self.drop(site))
+        ops.gemm(df, b.t[tag + "h"], self.G(lp + "linear2.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear2.bias"), workspace=ws)
+        dx = b.get(tag + "dxf", (M, d), self.dt)
+        ops.gemm(dhpre, self.W(lp + "linear1.weight"), dx, ta=False, tb=False, addend=ds_res)
+        ops.gemm(dhpre, x, self.G(lp + "linear1.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear1.bias"), workspace=ws)
+        return dx
+
+
+class EncoderEngine(_StackBase):
+    """MultiModalEncoder (one modality, 'avg' aggregation token, sinusoidal temporal encoding):
+    model/MMEncoder.py:244-276."""
+
+    def __init__(self, ps, prefix, cfg, seed, pe_buffer: torch.Tensor):
+        super().__init__(ps, prefix, cfg, seed)
+        self.pe = pe_buffer  # [1, 512, d] fp32 buffer `temp_emb.pe`
+        self._pe_rows = {}
+
+    def pe_rows(self, T):
+        r = self._pe_rows.get(T)
+        if r is None:
+            import numpy as np
+            idx = torch.from_numpy(np.linspace(0, T - 1, T).astype(np.int64)).to(self.dev)  # MMEncoder.py:98
+            r = torch.zeros(T + 1, self.cfg["d"], dtype=torch.float32, device=self.dev)
+            r[1:] = self.pe[0, idx, :]
+            self._pe_rows[T] = r
+        return r
+
+    def forward(self, feats: torch.Tensor, mask: Optional[torch.Tensor], training: bool) -> torch.Tensor:
+        """feats [B,T,Ein] fp32, mask [B,T] bool (True = padded) or None -> memory [B*(T+1), d]."""
+        B, T, Ein = feats.shape
+        d, L = self.cfg["d"], self.cfg["layers"]
+        self.p_drop = self.cfg["dropout"] if training else 0.0
+        b = self.buf((B, T))
+        self.cur, self.shape = b, (B, T)
+        Te, M = T + 1, B * (T + 1)
+        x_in = feats.reshape(B * T, Ein)
+        if self.dt != torch.float32:
+            x_in = ops.cast(x_in.contiguous(), b.get("feats_c", (B * T, Ein), self.dt))
+        else:
+            x_in = x_in.contiguous()
+        b.t["x_in"] = x_in
+        u = b.get("u", (B * T, d), self.dt)
+        ops.gemm(x_in, self.W("unify.0.weight"), u, bias=self.F("unify.0.bias"))
+        x = ops.enc_frontend_fwd(u, self.pe_rows(T), b.get("x0", (M, d), self.dt), B, T)
+        kpm = None
+        if mask is not None:
+            kpm = b.get("kpm", (B, Te), torch.uint8)
+            kpm[:, 0] = 0
+            kpm[:, 1:] = mask
+        b.t["kpm_used"] = kpm
+        for l in range(L):
+            lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
+            b.t[tag + "x"] = x
+            a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, B, Te, Te, False, kpm, site + 1)
+            x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+            f = self._ffn_fwd(b, tag + "ff.", lp, x1, site + 3)
+            x = self._ln_fwd(b, tag + "n2.", lp + "norm2.", f, x1, site + 4)
+        b.t["x_last"] = x
+        return self._ln_fwd(b, "nf.", "transformer_encoder.norm.", x, None, None)
+
+    def backward(self, dmem: torch.Tensor):
+        b = self.cur
+        B, T = self.shape
+        Te, L = T + 1, self.cfg["layers"]
+        kpm = b.t["kpm_used"]
+        dx, _ = self._ln_bwd(b, "nf.", "transformer_encoder.norm.", dmem, b.t["x_last"], None, None)
+        for l in reversed(range(L)):
+            lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
+            x, x1 = b.t[tag + "x"], b.t[tag + "n1.y"]
+            ds2, df = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx, b.t[tag + "ff.f"], x1, site + 4)
+            dx1 = self._ffn_bwd(b, tag + "ff.", lp, df, x1, site + 3, ds2)
+            ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
+            dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
+        du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
+        ops.gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"),
+                 workspace=self.gemm_ws())
+
+
+class DecoderEngine(_StackBase):
+    """CapDecoder: embedding + positional table, decoder stack, generator, SCE loss
+    (model/CapDecoder.py:34-60)."""
+
+    def __init__(self, ps, prefix, cfg, seed, pos_buffer: torch.Tensor):
+        super().__init__(ps, prefix, cfg, seed)
+        self.pos = pos_buffer  # [5000, d] fp32 buffer
+        self.V = cfg["vocab"]
+        self.Vp = (self.V + 31) // 32 * 32
+
+    def _run_stack(self, b, mem, Bn, Te, ids, Sd, kpm):
+        """Embedding + decoder layers + final LayerNorm over the first Sd tokens of each ids row."""
+        d, L = self.cfg["d"], self.cfg["layers"]
+        M = Bn * Sd
+        x = ops.embed_fwd(ids, Sd, self.F("tgt_to_emb.weight"), self.pos, b.get("x0", (M, d), self.dt), dropout=self.drop(EMB_SITE))
+        for l in range(L):
+            lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
+            b.t[tag + "x"] = x
+            a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, Bn, Sd, Sd, True, kpm, site + 1)
+            x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+            c = self._attn_block_fwd(b, tag + "ca.", lp + "multihead_attn.", x1, mem, Bn, Sd, Te, False, None, site + 3, self_attn=False)
+            x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, site + 4)
+            f = self._ffn_fwd(b, tag + "ff.", lp, x2, site + 5)
+            x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, site + 6)
+        b.t["x_last"] = x
+        return self._ln_fwd(b, "nf.", "decoder.norm.", x, None, None)
+
+    def forward(self, mem: torch.Tensor, Bn: int, Te: int, ids: torch.Tensor, training: bool, want_logits=False):
+        """mem [B*Te, d] compute dtype; ids int64 [B,S] (pads = pad_id).  Returns (loss[1] fp32, logits or None).
+        The logits gradient is produced in the same pass (in place when logits are not requested)."""
+        pad = self.cfg["pad_id"]
+        S = ids.shape[1]
+        Sd, M = S - 1, Bn * (S - 1)
+        self.p_drop = self.cfg["dropout"] if training else 0.0
+        b = self.buf((Bn, Te, S))
+        self.cur, self.shape = b, (Bn, Te, S)
+        b.t["ids"], b.t["mem"] = ids, mem
+        kpm = b.get("kpm", (Bn, Sd), torch.uint8)
+        torch.eq(ids[:, :-1], pad, out=kpm.view(torch.bool))
+        y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
+        logits = b.get("logits", (M, self.Vp), self.dt)
+        ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
+        loss = b.get("loss", (1,), torch.float32)
+        dlogits = b.get("dlogits", (M, self.Vp), self.dt) if want_logits else logits
+        ops.sce_loss(logits, self.V, ids[:, 1:], Sd, pad, self.cfg["sce_loss_alpha"], loss, dlogits,
+                     b.get("row_ws", (2 * M + 2,), torch.float32))
+        b.t["dlogits_used"] = dlogits
+        return loss, (logits if want_logits else None)
+
+    def decode_word(self, mem: torch.Tensor, Bn: int, Te: int, ys: torch.Tensor) -> torch.Tensor:
+        """Reference algorithm of CapDecoder.decode_word (CapDecoder.py:62-79): re-run the decoder over
+        ALL t tokens so far (causal mask, no padding mask), generator on the last position -> [B, V]."""
+        d, t = self.cfg["d"], ys.shape[1]
+        self.p_drop = 0.0
+        b = self.buf(("decode", Bn, Te, t))
+        y = self._run_stack(b, mem, Bn, Te, ys, t, None)
+        last = y.view(Bn, t, d)[:, t - 1, :]           # strided [B, d] view (lda = t*d): no gather copy
+        logits = b.get("logits1", (Bn, self.Vp), self.dt)
+        ops.gemm(last, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
+        return logits[:, :self.V]
+
+    def backward(self) -> torch.Tensor:
+        """d(loss) = 1.  Returns d(memory) [B*Te, d]."""
+        b = self.cur
+        Bn, Te, S = self.shape
+        d, L, pad = self.cfg["d"], self.cfg["layers"], self.cfg["pad_id"]
+        Sd, M = S - 1, Bn * (S - 1)
+        mem, ids, kpm = b.t["mem"], b.t["ids"], b.t["kpm"]
+        dl, y = b.t["dlogits_used"], b.t["nf.y"]
+        dy = b.get("dy", (M, d), self.dt)
+        ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V)
+        ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
+                 workspace=self.gemm_ws())
+        dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
+        dmem = b.get("dmem", (Bn * Te, d), self.dt)
+        for l in reversed(range(L)):
+            lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
+            x, x1, x2 = b.t[tag + "x"], b.t[tag + "n1.y"], b.t[tag + "n2.y"]
+            ds3, df = self._ln_bwd(b, tag + "n3.", lp + "norm3.", dx, b.t[tag + "ff.f"], x2, site + 6)
+            dx2 = self._ffn_bwd(b, tag + "ff.", lp, df, x2, site + 5, ds3)
+            ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
+            dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,
+                                       False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
+            ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
+            dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+        ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
+        return dmem

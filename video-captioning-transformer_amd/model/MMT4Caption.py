@@ -1,0 +1,201 @@
+"""MMT4Caption -- drop-in for the reference's model/MMT4Caption.py:15-211 on the caption task.
+
+Same constructor (`MMT4Caption(cfg['model'], device)`), `forward(video_feats, video_masks, captions)`,
+`caption_forward`, `greedy_decode`, `mode`, attributes (`cap_preprocessor`, `cap_decoder`,
+`video_encoder`, `matching`, `device`, `f_type`) and state_dict keys.  All parameters live in ONE
+flat fp32 buffer laid out in gradient-ready order (with a matching flat gradient buffer and a bf16
+shadow), so the data-parallel gradient exchange and the optimizer work on contiguous slices."""
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..engine import ParamSet
+from .CapDecoder import CapDecoder, grad_ready_order_decoder
+from .CapPreprocessor import CapPreprocessor
+from .Matching import Matching, TextEncoder
+from .MMEncoder import MultiModalEncoder, grad_ready_order_encoder
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+class _CaptionFn(torch.autograd.Function):
+    """loss = caption_forward(...) as ONE autograd node: forward = encoder + decoder + loss kernels,
+    backward = the explicit reverse schedule; gradients land in the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, feats, mask, ids, *params):
+        ctx.model = model
+        return model._forward_loss(feats, mask, ids, model.training)[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        m = ctx.model
+        m._backward()
+        m._ps.install_grads()
+        if not m._unit_loss_grad:
+            m._ps.gflat.mul_(gloss)
+        return (None, None, None, None) + (None,) * len(m._ps.names)
+
+
+class MMT4Caption(nn.Module):
+    def __init__(self, model_config: dict, device=torch.device("cuda"), compute_dtype=None):
+        super().__init__()
+        self.device = device
+        self.model_config = model_config
+        self.loss_beta = model_config["loss_beta"]
+        self.f_type = None
+        cd = compute_dtype or model_config.get("compute_dtype") or os.environ.get("VCT_COMPUTE_DTYPE", "bf16")
+        self.compute_dtype = _DTYPES[cd] if isinstance(cd, str) else cd
+
+        self.cap_preprocessor = CapPreprocessor(model_config["tokenizer"], device=device,
+                                                vocab_size=model_config.get("vocab_size"))
+        self.text_encoder = TextEncoder(model_config["text_enc_type"], device=device)
+        dec_cfg, enc_cfg = model_config["caption_decoder"], model_config["video_encoder"]
+        self.cap_decoder = CapDecoder(
+            num_layers=dec_cfg["layer"], embed_dim=model_config["embed_dim"], nhead=dec_cfg["nhead"],
+            dim_feedforward=dec_cfg["feedforward"], dropout=model_config["dropout"],
+            vocab_size=self.cap_preprocessor.tokenizer.vocab_size, pad_id=self.cap_preprocessor.pad_id,
+            sce_loss_alpha=dec_cfg["sce_loss_alpha"], custom_decoder_type=dec_cfg.get("layer_type", None),
+            activation=model_config["activation"], device=device, compute_dtype=self.compute_dtype)
+        if enc_cfg.get("type", "mme") != "mme":
+            raise NotImplementedError("video_encoder.type 'simple'/'hmme' are outside the accelerated caption path")
+        mme = enc_cfg["mme"]
+        self.video_encoder = MultiModalEncoder(
+            d_feats=model_config["modal_shape"], d_model=model_config["embed_dim"], nhead=enc_cfg["nhead"],
+            dim_feedforward=enc_cfg["feedforward"], num_encoder_layers=enc_cfg["layer"], dropout=model_config["dropout"],
+            activation=model_config["activation"], global_type=mme["aggregation"],
+            modal_different=mme.get("modal_different", True), temporal_type=mme.get("temporal", "encoding"),
+            do_norm=mme.get("do_norm", False), device=device, compute_dtype=self.compute_dtype)
+        if model_config.get("matching", None) is not None:
+            self.matching = Matching((model_config["embed_dim"], self.text_encoder.dim),
+                                     enable_tem=model_config["matching"]["enable_tem"],
+                                     loss=model_config["matching"]["matching_loss"],
+                                     loss_tem=model_config["matching"].get("temperature", None), device=device)
+        self._ps: Optional[ParamSet] = None
+        self._unit_loss_grad = False
+        self._seed = None
+        self._build_flat()
+
+    # ---- flat parameter storage --------------------------------------------------------------------
+    def _build_flat(self):
+        named = dict(self.named_parameters())
+        order = (grad_ready_order_decoder("cap_decoder.", self.cap_decoder.cfg["layers"]) +
+                 grad_ready_order_encoder("video_encoder.", self.video_encoder.cfg["layers"]))
+        order += [n for n in named if n not in set(order)]   # matching.* (not on the caption path)
+        dev = named[order[0]].device
+        self._ps = ParamSet([(n, named[n]) for n in order], dev, self.compute_dtype, no_shadow=("cap_decoder.tgt_to_emb.weight",))
+        if self._seed is None or self._seed.device != dev:
+            self._seed = torch.tensor([torch.initial_seed() & 0x7FFFFFFF], dtype=torch.int32, device=dev)
+        self.cap_decoder._bind(self._ps, "cap_decoder.", self._seed, self._build_flat)
+        self.video_encoder._bind(self._ps, "video_encoder.", self._seed, self._build_flat)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if self._ps is not None and not self._ps.intact():
+            self._build_flat()
+        return out
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._ps.flat
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        return self._ps.gflat
+
+    def grad_buckets(self):
+        """Contiguous [start, end) element ranges of the flat gradient buffer in the order the backward
+        pass completes them: generator | decoder stack | token embedding | encoder (+ rest)."""
+        ps, o = self._ps, self._ps.offsets
+        emb = "cap_decoder.tgt_to_emb.weight"
+        dec0 = o["cap_decoder.decoder.norm.weight"]
+        enc0 = o["video_encoder.transformer_encoder.norm.weight"]
+        return [(0, dec0), (dec0, o[emb]), (o[emb], enc0), (enc0, ps.total)]
+
+    # ---- engine-level forward/backward (no autograd) ------------------------------------------------
+    def _forward_loss(self, feats, mask, ids, training, want_logits=False):
+        if not self._ps.intact():
+            self._build_flat()
+        self._ps.refresh_shadow()
+        enc, dec = self.video_encoder._engine(), self.cap_decoder._engine()
+        mem = enc.forward(feats, mask, training)
+        loss, logits = dec.forward(mem, feats.shape[0], feats.shape[1] + 1, ids, training, want_logits=want_logits)
+        return loss, logits
+
+    def _backward(self):
+        dmem = self.cap_decoder._engine().backward()
+        self.video_encoder._engine().backward(dmem)
+
+    def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
+        """Fast path used by the trainer and bench: forward + backward as one static kernel schedule
+        (hipGraph-capturable, no autograd tape).  Gradients are WRITTEN (not accumulated) into the flat
+        gradient buffer, whose views are installed as `.grad`.  Returns the loss tensor [1]."""
+        loss, _ = self._forward_loss(feats, mask, ids, self.training)
+        self._backward()
+        return loss
+
+    # ---- reference API -----------------------------------------------------------------------------
+    def forward(self, video_feats: List[torch.Tensor], video_masks: List[torch.Tensor], captions):
+        if self.f_type == "caption":
+            return self.caption_forward(video_feats, video_masks, captions)
+        if self.f_type in ("match", "cross"):
+            raise NotImplementedError("the video-text matching task is outside the MI355X caption path")
+        raise ValueError
+
+    def caption_forward(self, video_feats, video_masks, captions):
+        text_ts, _text_mask_ts = self.cap_preprocessor(captions)
+        mask = video_masks[0] if video_masks is not None else None
+        feats = video_feats[0]
+        if not torch.is_grad_enabled():
+            return self._forward_loss(feats, mask, text_ts, self.training)[0][0].clone()
+        return _CaptionFn.apply(self, feats, mask, text_ts, *[self._ps.params[n] for n in self._ps.names]).clone().reshape(())
+
+    @torch.no_grad()
+    def greedy_decode(self, video_feat: List[torch.Tensor], video_masks: Optional[List[torch.Tensor]] = None,
+                      max_len: int = 30) -> List[str]:
+        ys = self.greedy_decode_ids(video_feat, video_masks, max_len)
+        end_id = self.cap_preprocessor.end_id
+        result = []
+        for idx_cap in ys.tolist():
+            end_count = -1
+            for i, idx in enumerate(idx_cap):
+                if idx == end_id:
+                    end_count = i
+                    break
+            idx_cap = idx_cap[1:end_count]   # reference quirk kept: without [SEP] the last token is dropped
+            toks = self.cap_preprocessor.tokenizer.convert_ids_to_tokens(idx_cap)
+            result.append(self.cap_preprocessor.tokenizer.convert_tokens_to_string(toks))
+        return result
+
+    @torch.no_grad()
+    def greedy_decode_ids(self, video_feat, video_masks=None, max_len: int = 30) -> torch.Tensor:
+        """The id matrix ys [B, <=max_len] of MMT4Caption.greedy_decode (MMT4Caption.py:159-172)."""
+        was_training = self.training
+        self.eval()
+        try:
+            from .. import decode
+            return decode.greedy_decode_ids(self, video_feat[0], video_masks[0] if video_masks is not None else None, max_len)
+        finally:
+            self.train(was_training)
+
+    def beam_decode(self):
+        pass
+
+    def mode(self, forward_type="caption") -> None:
+        self.f_type = forward_type
+        matching = getattr(self, "matching", None)
+        mparams = list(matching.parameters()) if matching is not None else []
+        if forward_type == "caption":
+            flags = (True, False)
+        elif forward_type == "match":
+            flags = (False, True)
+        elif forward_type == "cross":
+            flags = (True, True)
+        else:
+            raise ValueError
+        for p in self.cap_decoder.parameters():
+            p.requires_grad = flags[0]
+        for p in mparams:
+            p.requires_grad = flags[1]
