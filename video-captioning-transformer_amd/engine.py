@@ -345,7 +345,7 @@ class DecoderEngine(_StackBase):
         torch.eq(ids[:, :-1], pad, out=kpm.view(torch.bool))
         y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
         logits = b.get("logits", (M, self.Vp), self.dt)
-        ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
+        ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, tag="gen_fwd")
         loss = b.get("loss", (1,), torch.float32)
         dlogits = b.get("dlogits", (M, self.Vp), self.dt) if want_logits else logits
         ops.sce_loss(logits, self.V, ids[:, 1:], Sd, pad, self.cfg["sce_loss_alpha"], loss, dlogits,
@@ -365,8 +365,9 @@ class DecoderEngine(_StackBase):
         ops.gemm(last, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
         return logits[:, :self.V]
 
-    def backward(self) -> torch.Tensor:
-        """d(loss) = 1.  Returns d(memory) [B*Te, d]."""
+    def backward(self, bucket_ready=None) -> torch.Tensor:
+        """d(loss) = 1.  Returns d(memory) [B*Te, d].  bucket_ready(i) is called when gradient bucket i of
+        MMT4Caption.grad_buckets() is complete (0 generator, 1 decoder stack, 2 token embedding)."""
         b = self.cur
         Bn, Te, S = self.shape
         d, L, pad = self.cfg["d"], self.cfg["layers"], self.cfg["pad_id"]
@@ -374,9 +375,11 @@ class DecoderEngine(_StackBase):
         mem, ids, kpm = b.t["mem"], b.t["ids"], b.t["kpm"]
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
-        ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V)
+        ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, tag="gen_dx")
         ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
-                 workspace=self.gemm_ws())
+                 workspace=self.gemm_ws(), tag="gen_dw")
+        if bucket_ready is not None:
+            bucket_ready(0)
         dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
         dmem = b.get("dmem", (Bn * Te, d), self.dt)
         for l in reversed(range(L)):
@@ -389,5 +392,9 @@ class DecoderEngine(_StackBase):
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+        if bucket_ready is not None:
+            bucket_ready(1)
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
+        if bucket_ready is not None:
+            bucket_ready(2)
         return dmem

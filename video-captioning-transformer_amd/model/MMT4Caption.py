@@ -124,16 +124,19 @@ class MMT4Caption(nn.Module):
         loss, logits = dec.forward(mem, feats.shape[0], feats.shape[1] + 1, ids, training, want_logits=want_logits)
         return loss, logits
 
-    def _backward(self):
-        dmem = self.cap_decoder._engine().backward()
+    def _backward(self, bucket_ready=None):
+        dmem = self.cap_decoder._engine().backward(bucket_ready)
         self.video_encoder._engine().backward(dmem)
+        if bucket_ready is not None:
+            bucket_ready(3)
 
-    def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
+    def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor,
+                           bucket_ready=None) -> torch.Tensor:
         """Fast path used by the trainer and bench: forward + backward as one static kernel schedule
         (hipGraph-capturable, no autograd tape).  Gradients are WRITTEN (not accumulated) into the flat
         gradient buffer, whose views are installed as `.grad`.  Returns the loss tensor [1]."""
         loss, _ = self._forward_loss(feats, mask, ids, self.training)
-        self._backward()
+        self._backward(bucket_ready)
         return loss
 
     # ---- reference API -----------------------------------------------------------------------------

@@ -8,6 +8,10 @@ from . import _lib as L
 
 Drop = Optional[Tuple[torch.Tensor, int, float]]  # (seed tensor uint32[1] on device, site id, p)
 
+# Optional live timing of tagged launches (bench.py roofline): event_taps[tag] = list of (start, end)
+# torch.cuda.Event pairs recorded on the launch stream around the kernel.  Empty dict = no overhead.
+event_taps = {}
+
 
 def _drop(d: Drop):
     if d is None or d[2] <= 0.0:
@@ -24,7 +28,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
          bias: Optional[torch.Tensor] = None, act: Optional[str] = None, preact: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
          bias_grad: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, split_k: int = 0,
-         n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None) -> torch.Tensor:
+         n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None,
+         tag: Optional[str] = None) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
     tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
     logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns)."""
@@ -60,7 +65,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     d.split_k = split_k
+    tap = event_taps.get(tag) if tag is not None and event_taps else None
+    if tap is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.vct_gemm(d, L.stream_ptr()), "vct_gemm")
+    if tap is not None:
+        e1.record()
+        tap.append((e0, e1))
     return out
 
 

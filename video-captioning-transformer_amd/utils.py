@@ -1,0 +1,55 @@
+"""Host-side helpers mirroring the reference's utils.py (mask builder, JSON config, seeding,
+process-group setup)."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+
+def generate_square_subsequent_mask(sz: int) -> torch.Tensor:
+    """Float [sz,sz] causal mask: 0 on/below the diagonal, -inf above (reference utils.py:63-66).
+    The attention kernel bakes this predicate in (causal=1); the function exists for API parity."""
+    return torch.triu(torch.full((sz, sz), float("-inf")), diagonal=1)
+
+
+class Config:
+    """JSON config loader (reference utils.py:82-89); `.data['model']` feeds MMT4Caption unchanged."""
+
+    def __init__(self, path: str):
+        with open(path) as f:
+            self.data = json.load(f)
+
+    def check(self):
+        if self.data["model"]["video_encoder"].get("type", "mme") != "mme":
+            raise ValueError("only the 'mme' video encoder is on the accelerated caption path")
+
+
+def setup_seed(seed: int):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def configure_hardware(backend: str = None):
+    """One process per GPU (reference utils.py:126-149).  Reads RANK/LOCAL_RANK/WORLD_SIZE from the
+    launcher env; backend 'nccl' is RCCL on ROCm, 'gloo' for CPU tests.  Returns (device, rank, world)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available() and backend != "gloo"
+    if use_cuda:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if use_cuda else {}
+        dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
+    return device, rank, world
