@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
+#include <type_traits>
 #include "../../include/vct_hip.h"
 
 namespace vct {
@@ -115,6 +117,16 @@ template <int NW> __device__ __forceinline__ float block_max(float v, float* red
 // (Semantics confirmed on hardware by tools/hw_probe.hip.)
 __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- guarantees that arrays
+// indexed by the loop variable stay in registers (a runtime-indexed accumulator array goes to scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 template <typename T> struct DTypeOf;

@@ -166,34 +166,47 @@ __global__ void count_valid_kernel(int N, int S, const int64_t* __restrict__ lab
 
 constexpr float SCE_C = 9.210340371976184f;  // -log(1e-4): loss.py:86-88 off-target log(clamp(onehot))
 
+// The row is staged in LDS in its STORAGE type (bf16 rows take 61 KB -> two workgroups per CU, so one
+// row's HBM latency hides under the other's passes); exp(x - max) is recomputed in each pass.
 template <typename T>
 __global__ __launch_bounds__(1024) void sce_loss_kernel(int N, int S, int V, const T* __restrict__ logits, int64_t ldl,
                                                         const int64_t* __restrict__ labels, int64_t lbstride,
                                                         int64_t pad_id, float alpha, T* __restrict__ dlogits, int64_t ld_dl,
                                                         float* __restrict__ row_ws) {
-  extern __shared__ __attribute__((aligned(16))) float row[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char row_raw[];
+  T* row = reinterpret_cast<T*>(row_raw);
   __shared__ float red[16];
+  constexpr int VEC = EV<T>::VEC;
+  using P = PackT<T, VEC>;
   const int n = blockIdx.x, tid = threadIdx.x;
   const T* x = logits + (size_t)n * ldl;
   const int64_t y = labels[(size_t)(n / S) * lbstride + (n % S)];
   const bool valid = (y != pad_id);
   const float nvalid = row_ws[2 * N];
-  // pass 1: stage the row, running max
+  const int nv = (V + VEC - 1) / VEC;   // LDS row is padded to a whole vector
+  const bool vec_in = (ldl % VEC == 0) && (((uintptr_t)logits & 15) == 0);
+  // pass 1: stage the row (16-byte loads), running max
   float mx = -INFINITY;
-  for (int j = tid; j < V; j += 1024) {
-    const float v = to_f<T>(x[j]);
-    row[j] = v;
-    mx = fmaxf(mx, v);
+  if (vec_in) {
+    for (int vi = tid; vi < nv; vi += 1024) {
+      const P pk = *reinterpret_cast<const P*>(x + vi * VEC);
+      *reinterpret_cast<P*>(row + vi * VEC) = pk;
+#pragma unroll
+      for (int j = 0; j < VEC; j++)
+        if (vi * VEC + j < V) mx = fmaxf(mx, to_f<T>(pk.v[j]));
+    }
+  } else {
+    for (int j = tid; j < V; j += 1024) { const T v = x[j]; row[j] = v; mx = fmaxf(mx, to_f<T>(v)); }
   }
-  mx = block_max<16>(mx, red);
-  const float xy = row[y];  // visible: block_max synchronised
-  __syncthreads();
-  // pass 2: e = exp(x - max), sum
+  mx = block_max<16>(mx, red);   // also makes the staged row visible
+  const float xy = to_f<T>(row[y]);
+  // pass 2: sum of exp(x - max)
   float se = 0.0f;
-  for (int j = tid; j < V; j += 1024) {
-    const float e = expf(row[j] - mx);
-    row[j] = e;
-    se += e;
+  for (int vi = tid; vi < nv; vi += 1024) {
+    const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; j++)
+      if (vi * VEC + j < V) se += __expf(to_f<T>(pk.v[j]) - mx);
   }
   se = block_sum<16>(se, red);
   const float inv = 1.0f / se;
@@ -201,32 +214,52 @@ __global__ __launch_bounds__(1024) void sce_loss_kernel(int N, int S, int V, con
   // pass 3: Q = sum_{j != y, p_j >= 1e-7} p_j ; cnt = #{j != y : p_j < 1e-7}
   float q = 0.0f, cnt = 0.0f;
   if (alpha != 1.0f) {
-    for (int j = tid; j < V; j += 1024) {
-      if (j != y) {
-        const float pj = row[j] * inv;
-        if (pj >= 1e-7f) q += pj; else cnt += 1.0f;
+    for (int vi = tid; vi < nv; vi += 1024) {
+      const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const int c = vi * VEC + j;
+        if (c < V && c != y) {
+          const float pj = __expf(to_f<T>(pk.v[j]) - mx) * inv;
+          if (pj >= 1e-7f) q += pj; else cnt += 1.0f;
+        }
       }
     }
     q = block_sum<16>(q, red);
     cnt = block_sum<16>(cnt, red);
   }
   if (tid == 0) {
-    row_ws[n] = valid ? (mx + logf(se)) - xy : 0.0f;
+    row_ws[n] = valid ? (mx + __logf(se)) - xy : 0.0f;
     row_ws[N + n] = SCE_C * (q + 1e-7f * cnt);
   }
   if (dlogits == nullptr) return;
   // pass 4: gradient  a*(p - 1[j==y]) + (beta/N) * p * (G_j - c*Q),  G_j = c*[j != y][p_j >= 1e-7]
   const float a = valid ? alpha / nvalid : 0.0f;
   const float bn = (alpha != 1.0f) ? beta / (float)N : 0.0f;
+  const float cq = SCE_C * q;
   T* dx = dlogits + (size_t)n * ld_dl;
-  for (int j = tid; j < (int)ld_dl; j += 1024) {
-    float gval = 0.0f;
-    if (j < V) {
-      const float pj = row[j] * inv;
-      const float G = (j != y && pj >= 1e-7f) ? SCE_C : 0.0f;
-      gval = a * (pj - (j == y ? 1.0f : 0.0f)) + bn * pj * (G - SCE_C * q);
+  auto grad_of = [&](int j, float xv) -> float {
+    if (j >= V) return 0.0f;
+    const float pj = __expf(xv - mx) * inv;
+    const float G = (j != y && pj >= 1e-7f) ? SCE_C : 0.0f;
+    return a * (pj - (j == y ? 1.0f : 0.0f)) + bn * pj * (G - cq);
+  };
+  if ((ld_dl % VEC == 0) && (((uintptr_t)dlogits & 15) == 0)) {
+    const int nvo = (int)(ld_dl / VEC);
+    for (int vi = tid; vi < nvo; vi += 1024) {
+      P o;
+      if (vi < nv) {
+        const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o.v[j] = from_f<T>(grad_of(vi * VEC + j, to_f<T>(pk.v[j])));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o.v[j] = from_f<T>(0.0f);
+      }
+      *reinterpret_cast<P*>(dx + vi * VEC) = o;
     }
-    dx[j] = from_f<T>(gval);
+  } else {
+    for (int j = tid; j < (int)ld_dl; j += 1024) dx[j] = from_f<T>(j < V ? grad_of(j, to_f<T>(row[j])) : 0.0f);
   }
 }
 
@@ -366,12 +399,13 @@ extern "C" int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, 
                             int64_t ld_dl, float* row_ws, void* stream) {
   if (!dt_ok(dtype) || !logits || !labels || !loss_out || !row_ws) return VCT_E_ARG;
   if (N <= 0 || S <= 0 || V <= 0 || N % S) return VCT_E_SHAPE;
-  if ((size_t)V * 4 > 160 * 1024 - 256) return VCT_E_SHAPE;  // row must fit in one CU's LDS
+  const size_t esz = dtype == VCT_BF16 ? 2 : 4;
+  if (((size_t)V + 8) * esz > 160 * 1024 - 256) return VCT_E_SHAPE;  // row must fit in one CU's LDS
   if (ldl < V || (dlogits && ld_dl < V)) return VCT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, st, N, S, labels, label_batch_stride, pad_id, row_ws + 2 * (size_t)N);
   VCT_CHECK_LAUNCH();
-  const size_t shmem = (size_t)V * 4;
+  const size_t shmem = (((size_t)V + 7) / 8 * 8 + 8) * esz;
   if (dtype == VCT_BF16) {
     auto kfn = sce_loss_kernel<bf16_t>;
     static int attr_bf16 = 0;

@@ -13,26 +13,9 @@
 //    residual-gradient accumulate, activation-derivative multiply, bias gradient (row sums of op(A)
 //    via one extra MFMA against a ones fragment).
 #include "vct_common.h"
+#include "vct_gemm_params.h"
 
 namespace vct {
-
-struct GemmP {
-  const void* A; const void* B; void* C;
-  long lda, ldb, ldc;
-  int M, N, K;
-  int kt_per_split;  // BK tiles per blockIdx.z
-  int tiles_n;
-  int act;        // forward activation applied after bias
-  int dact_kind;  // activation whose derivative multiplies the result (dact != nullptr)
-  const float* bias;
-  void* preact; long ld_preact;
-  const void* addend; long ld_addend;
-  const void* dact; long ld_dact;
-  const uint32_t* seed; uint32_t site; float p_drop;
-  float* bias_grad;
-  float* partial;       // != nullptr: split-K mode, raw accumulators to partial[z][M*N]
-  float* bias_partial;  // split-K mode: [z][M]
-};
 
 template <typename TI> struct GemmCfg;
 template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8, KPAD = 8; };
@@ -140,8 +123,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   using SB = Stager<TI, B_MC, BN>;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
 
-  __shared__ __attribute__((aligned(16))) TI lds_a[SA::LDS_ELEMS];
-  __shared__ __attribute__((aligned(16))) TI lds_b[SB::LDS_ELEMS];
+  // one LDS block: [A tile | B tile] during the K loop, then per-wave fp32 staging slabs for the epilogue
+  constexpr int STG_STRIDE = WN + 4;                       // floats per staged row
+  constexpr int STG_BYTES = 4 * 16 * STG_STRIDE * 4;       // 4 waves x 16 rows
+  constexpr int TILE_BYTES = (SA::LDS_ELEMS + SB::LDS_ELEMS) * (int)sizeof(TI);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[TILE_BYTES > STG_BYTES ? TILE_BYTES : STG_BYTES];
+  TI* lds_a = reinterpret_cast<TI*>(lds_raw);
+  TI* lds_b = lds_a + SA::LDS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -221,64 +209,121 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
   }
 
-  // ---- epilogue: C layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r -------------
+  // ---- epilogue ------------------------------------------------------------------------------
+  // The C fragment of a 16x16 MFMA holds, per lane, ONE column (lane & 15) and four rows
+  // ((lane >> 4) * 4 + r): storing it directly means 2/4-byte scattered stores.  Each wave instead
+  // transposes one 16-row slab of its sub-tile through a private fp32 LDS slab and every lane then
+  // owns VO consecutive columns of one row: bias / activation / dropout / addend / derivative are
+  // applied on that vector and it is stored with ONE 16-byte instruction.
   const int c16 = lane & 15, g4 = (lane >> 4) * 4;
-  if (p.partial != nullptr) {
-    float* part = p.partial + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N;
+  if (do_bias_grad && c16 == 0) {
+    float* bg = p.partial != nullptr ? p.bias_partial + (size_t)blockIdx.z * p.M : p.bias_grad;
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = m0 + wm * WM + i * 16 + g4 + r, col = n0 + wn * WN + j * 16 + c16;
-          if (row < p.M && col < p.N) part[(size_t)row * p.N + col] = acc[i][j][r];
-        }
-    if (do_bias_grad && c16 == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = m0 + wm * WM + i * 16 + g4 + r;
-          if (row < p.M) p.bias_partial[(size_t)blockIdx.z * p.M + row] = accb[i][r];
-        }
-    }
-    return;
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * WM + i * 16 + g4 + r;
+        if (row < p.M) bg[row] = accb[i][r];
+      }
   }
+  __syncthreads();  // every wave is done with the operand tiles: LDS becomes staging space
+  float* stg = reinterpret_cast<float*>(lds_raw) + wave * 16 * STG_STRIDE;
+  const bool part = p.partial != nullptr;
+  constexpr int VO = 16 / (int)sizeof(TO);          // output elements per 16-byte store
+  constexpr int CPR = WN / VO;                      // 16-byte chunks per staged row
+  constexpr int CPL = 16 * CPR / 64;                // chunks per lane
+  static_assert(CPL >= 1, "staging geometry");
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* preact = reinterpret_cast<TO*>(p.preact);
   const TO* addend = reinterpret_cast<const TO*>(p.addend);
   const TO* dact = reinterpret_cast<const TO*>(p.dact);
+  float* partC = part ? p.partial + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : nullptr;
+  const long ldo = part ? (long)p.N : p.ldc;
+  const bool vec_ok = (ldo % VO == 0) && (!part ? (((uintptr_t)p.C & 15) == 0) : true) && ((p.N % 4) == 0 || !part);
+  // bias for this lane's columns: loaded ONCE, unconditionally (clamped), ahead of the staging loop --
+  // a conditional per-element load would make hipcc branch + s_waitcnt vmcnt(0) around every element
+  float bvec[CPL][VO];
 #pragma unroll
-  for (int i = 0; i < TM; i++)
+  for (int c = 0; c < CPL; c++)
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int col = n0 + wn * WN + j * 16 + c16;
-      const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.0f;
+    for (int q = 0; q < VO; q++) bvec[c][q] = 0.0f;
+  if (p.bias != nullptr && !part) {   // ONE uniform branch around all the loads
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = m0 + wm * WM + i * 16 + g4 + r;
-        if (row < p.M && col < p.N) {
-          float v = acc[i][j][r] + bv;
-          if (preact != nullptr) preact[(size_t)row * p.ld_preact + col] = from_f<TO>(v);
-          v = act_f(p.act, v);
-          if (dact != nullptr) v *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col]));
-          v *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
-          if (addend != nullptr) v += to_f<TO>(addend[(size_t)row * p.ld_addend + col]);
-          C[(size_t)row * p.ldc + col] = from_f<TO>(v);
+    for (int c = 0; c < CPL; c++) {
+      const int col = n0 + wn * WN + ((c * 64 + lane) % CPR) * VO;
+#pragma unroll
+      for (int q = 0; q < VO; q++) bvec[c][q] = p.bias[min(col + q, p.N - 1)];
+    }
+  }
+  struct alignas(16) OutV { TO e[VO]; };
+  static_for<TM>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    static_for<TN>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+#pragma unroll
+      for (int r = 0; r < 4; r++) stg[(g4 + r) * STG_STRIDE + j * 16 + c16] = acc[i][j][r];
+    });
+    // same-wave LDS write -> read: ordered by the wave's own lgkmcnt, no barrier needed
+    static_for<CPL>([&](auto CI) {
+      constexpr int c = decltype(CI)::value;
+      const int chunk = c * 64 + lane;
+      const int rr = chunk / CPR, cc = (chunk % CPR) * VO;
+      const int row = m0 + wm * WM + i * 16 + rr, col = n0 + wn * WN + cc;
+      float v[VO];
+#pragma unroll
+      for (int q = 0; q < VO; q += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stg + rr * STG_STRIDE + cc + q);
+        v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+      }
+      if (row >= p.M || col >= p.N) return;
+      const bool full = vec_ok && (col + VO <= p.N);
+      if (part) {
+        float* dst = partC + (size_t)row * p.N + col;
+        if (full) {
+#pragma unroll
+          for (int q = 0; q < VO; q += 4) *reinterpret_cast<f32x4*>(dst + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+        } else {
+          for (int q = 0; q < VO; q++) if (col + q < p.N) dst[q] = v[q];
+        }
+        return;
+      }
+      if (full) {
+        // fast path: every global access is an unconditional 16-byte vector
+        OutV dv, av, ov, pv;
+        const bool has_d = dact != nullptr, has_a = addend != nullptr;
+        if (has_d) dv = *reinterpret_cast<const OutV*>(dact + (size_t)row * p.ld_dact + col);
+        if (has_a) av = *reinterpret_cast<const OutV*>(addend + (size_t)row * p.ld_addend + col);
+#pragma unroll
+        for (int q = 0; q < VO; q++) {
+          float x = v[q] + bvec[c][q];
+          pv.e[q] = from_f<TO>(x);
+          x = act_f(p.act, x);
+          if (has_d) x *= dact_f(p.dact_kind, to_f<TO>(dv.e[q]));
+          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+          if (has_a) x += to_f<TO>(av.e[q]);
+          ov.e[q] = from_f<TO>(x);
+        }
+        *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+        if (preact != nullptr) {
+          if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
+          else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
+        }
+      } else {
+        // ragged tail (last partial vector of a row, or unaligned output): element-wise
+        for (int q = 0; q < VO; q++) {
+          if (col + q >= p.N) break;
+          float x = v[q] + bvec[c][q];
+          if (preact != nullptr) preact[(size_t)row * p.ld_preact + col + q] = from_f<TO>(x);
+          x = act_f(p.act, x);
+          if (dact != nullptr) x *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
+          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+          if (addend != nullptr) x += to_f<TO>(addend[(size_t)row * p.ld_addend + col + q]);
+          C[(size_t)row * p.ldc + col + q] = from_f<TO>(x);
         }
       }
-    }
-  if (do_bias_grad && c16 == 0) {
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = m0 + wm * WM + i * 16 + g4 + r;
-        if (row < p.M) p.bias_grad[row] = accb[i][r];
-      }
-  }
+    });
+  });
 }
 
 // deterministic split-K second pass: C[i] = sum_z partial[z][i] (fixed z order)
@@ -301,25 +346,44 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, TO* __re
   }
 }
 
-struct Plan { int bm; int split; int tiles_m, tiles_n, nkt, kt_per; };
+struct Plan { int bm, bn, nbuf; int split; int tiles_m, tiles_n, nkt, kt_per; };
 
 static bool gemm_can_split(const vct_gemm_desc* d) {
-  return d->out_dtype == VCT_F32 && d->bias == nullptr && d->act == VCT_ACT_NONE && d->preact == nullptr &&
+  return d->bias == nullptr && d->act == VCT_ACT_NONE && d->preact == nullptr &&
          d->addend == nullptr && d->dact_src == nullptr && !(d->seed != nullptr && d->p_drop > 0.0f);
 }
 
+// overrides for experiments: desc.reserved = tile + 10 * nbuf; tile 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64 (0 auto); nbuf 1..3 (0 default)
 static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   Plan pl;
-  const int BK = d->dtype == VCT_BF16 ? 64 : 16;
+  pl.nbuf = 2;
+  const bool bf = d->dtype == VCT_BF16;
+  const int BK = bf ? 64 : 16;
   pl.nkt = (d->K + BK - 1) / BK;
-  const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-  pl.bm = (t128 >= 384) ? 128 : 64;
+  auto tiles = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
+  if (bf) {
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    int pick = 3;
+    const int tsel = d->reserved % 10;
+    pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
+    if (tsel >= 1 && tsel <= 4) pick = tsel - 1;
+    else {
+      // measured on MI355X (tools/gemm_bench.py, cfg-B shapes): with K <= 2048 the kernel is bound by
+      // operand fetch + per-tile latency and 64x64 tiles (5 workgroups / CU) win; a long reduction
+      // (K >= 4096: the vocabulary / token dimension) amortises 128x128 tiles (+ split-K when legal)
+      pick = 3;
+      if (pl.nkt >= 64 && tiles(128, 128) >= 128) pick = 0;
+    }
+    pl.bm = cand[pick][0]; pl.bn = cand[pick][1];
+  } else {
+    pl.bm = pl.bn = (tiles(128, 128) >= 384) ? 128 : 64;
+  }
   pl.tiles_m = (d->M + pl.bm - 1) / pl.bm;
-  pl.tiles_n = (d->N + pl.bm - 1) / pl.bm;
-  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  pl.tiles_n = (d->N + pl.bn - 1) / pl.bn;
+  const long nt = (long)pl.tiles_m * pl.tiles_n;
   int split = 1;
   if (d->split_k > 1) split = d->split_k;
-  else if (d->split_k == 0 && tiles < 256 && pl.nkt >= 8) split = (int)((511 + tiles) / tiles);
+  else if (d->split_k == 0 && nt < 384 && pl.nkt >= 8) split = (int)((767 + nt) / nt);
   if (!gemm_can_split(d) || !have_ws) split = 1;
   if (split > pl.nkt / 2) split = pl.nkt / 2 > 0 ? pl.nkt / 2 : 1;
   if (split < 1) split = 1;
@@ -348,6 +412,8 @@ static int dispatch_layout(const vct_gemm_desc* d, const GemmP& p, int bm, dim3 
   }
 #undef VCT_L
 }
+
+int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st);
 
 }  // namespace vct
 
@@ -382,6 +448,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.kt_per_split = pl.kt_per;
+  p.tiles_m = pl.tiles_m;
   p.tiles_n = pl.tiles_n;
   p.act = d->dact_src != nullptr ? VCT_ACT_NONE : d->act;
   p.dact_kind = d->dact_src != nullptr ? d->act : VCT_ACT_NONE;
@@ -399,8 +466,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   const dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
   int rc;
   if (d->dtype == VCT_BF16) {
-    rc = d->out_dtype == VCT_BF16 ? dispatch_layout<bf16_t, bf16_t>(d, p, pl.bm, grid, st)
-                                  : dispatch_layout<bf16_t, float>(d, p, pl.bm, grid, st);
+    rc = gemm_bf16_v2_dispatch(d, p, pl.bm, pl.bn, pl.nbuf, grid, st);
   } else {
     if (d->out_dtype != VCT_F32) return VCT_E_ARG;
     rc = dispatch_layout<float, float>(d, p, pl.bm, grid, st);
@@ -410,8 +476,12 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   if (pl.split > 1) {
     const size_t total = (size_t)d->M * d->N;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p.partial,
-                       reinterpret_cast<float*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
+    if (d->out_dtype == VCT_F32)
+      hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p.partial,
+                         reinterpret_cast<float*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
+    else
+      hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p.partial,
+                         reinterpret_cast<bf16_t*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
     VCT_CHECK_LAUNCH();
   }
   return VCT_OK;

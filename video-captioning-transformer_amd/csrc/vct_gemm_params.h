@@ -1,0 +1,25 @@
+// Kernel-side parameter block shared by the GEMM translation units.
+#pragma once
+#include <stdint.h>
+
+namespace vct {
+
+struct GemmP {
+  const void* A; const void* B; void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int kt_per_split;  // K tiles per blockIdx.z
+  int tiles_m, tiles_n;
+  int act;        // forward activation applied after bias
+  int dact_kind;  // activation whose derivative multiplies the result (dact != nullptr)
+  const float* bias;
+  void* preact; long ld_preact;
+  const void* addend; long ld_addend;
+  const void* dact; long ld_dact;
+  const uint32_t* seed; uint32_t site; float p_drop;
+  float* bias_grad;
+  float* partial;       // != nullptr: split-K mode, raw accumulators to partial[z][M*N]
+  float* bias_partial;  // split-K mode: [z][M]
+};
+
+}  // namespace vct

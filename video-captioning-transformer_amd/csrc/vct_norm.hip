@@ -8,7 +8,7 @@
 
 namespace vct {
 
-constexpr int LN_ROWS_PER_WAVE = 8;
+constexpr int LN_ROWS_PER_WAVE = 2;   // 8 rows per 4-wave workgroup: enough workgroups to fill 256 CUs at M ~ 5k
 
 template <typename T> struct LnCfg;
 template <> struct LnCfg<float> { static constexpr int VEC = 4, MAXIT = 4; };
@@ -146,36 +146,65 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
       }
     }
   }
-  // column partials of this wave -> param_ws[gw][0][d] (dgamma), [gw][1][d] (dbeta)
+  // column partials: the 4 waves of the workgroup are summed through LDS (fixed order), then ONE
+  // partial row per workgroup goes to param_ws[block][0][d] (dgamma) / [block][1][d] (dbeta)
+  __shared__ float psum[3][2][1024];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
     const int vi = it * 64 + lane;
-    if (vi < nvec) {
+    if (vi < nvec && w > 0) {
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
-        param_ws[((size_t)gw * 2 + 0) * d + vi * VEC + j] = pg[it][j];
-        param_ws[((size_t)gw * 2 + 1) * d + vi * VEC + j] = pb[it][j];
+        psum[w - 1][0][vi * VEC + j] = pg[it][j];
+        psum[w - 1][1][vi * VEC + j] = pb[it][j];
+      }
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const int c = vi * VEC + j;
+          param_ws[((size_t)blockIdx.x * 2 + 0) * d + c] = pg[it][j] + psum[0][0][c] + psum[1][0][c] + psum[2][0][c];
+          param_ws[((size_t)blockIdx.x * 2 + 1) * d + c] = pb[it][j] + psum[0][1][c] + psum[1][1][c] + psum[2][1][c];
+        }
       }
     }
   }
 }
 
-__global__ void ln_param_finalize_kernel(int nws, int d, const float* __restrict__ ws, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * d) return;
-  const int which = c / d, col = c % d;
+// column sums of the per-workgroup partials: block = 16 columns x 16 row slices, fixed summation order
+__global__ __launch_bounds__(256) void ln_param_finalize_kernel(int nws, int d, const float* __restrict__ ws,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[16][17];
+  const int cx = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;   // column in [0, 2d): first d = dgamma, next d = dbeta
   float s = 0.0f;
-  for (int r = 0; r < nws; r++) s += ws[((size_t)r * 2 + which) * d + col];
-  (which == 0 ? dgamma : dbeta)[col] = s;
+  if (c < 2 * d) {
+    const int which = c / d, col = c % d;
+    for (int r = rg; r < nws; r += 16) s += ws[((size_t)r * 2 + which) * d + col];
+  }
+  red[rg][cx] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * d) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][cx];
+    (c < d ? dgamma : dbeta)[c % d] = t;
+  }
 }
 
 }  // namespace vct
 using namespace vct;
 
-extern "C" int vct_ln_ws_rows(int M) {
+extern "C" int vct_ln_ws_rows(int M) {   // partial rows = workgroups of the backward kernel
   const int waves = (M + LN_ROWS_PER_WAVE - 1) / LN_ROWS_PER_WAVE;
-  return ((waves + 3) / 4) * 4;
+  return (waves + 3) / 4;
 }
 
 static int ln_check(int dtype, int M, int d) {
@@ -214,7 +243,7 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
   if (!dy || !x || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta || !param_ws) return VCT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nws = vct_ln_ws_rows(M);
-  const dim3 grid(nws / 4);
+  const dim3 grid(nws);
   if (dtype == VCT_BF16)
     hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
                        (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop);
@@ -222,7 +251,7 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
     hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
                        (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -375,7 +375,7 @@ class DecoderEngine(_StackBase):
         mem, ids, kpm = b.t["mem"], b.t["ids"], b.t["kpm"]
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
-        ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, tag="gen_dx")
+        ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
         ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
                  workspace=self.gemm_ws(), tag="gen_dw")
         if bucket_ready is not None:
