@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce payload")
+    ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -116,7 +117,11 @@ def main():
     model.mode("caption")
     model.train()
     ex = GradExchange(model, payload_dtype=torch.bfloat16 if args.payload == "bf16" else None) if world > 1 else None
-    opt, _ = build_optimizer(TRAIN_CFG, model)
+    if args.torch_adam:
+        flat = torch.nn.Parameter(model.flat_params); flat.grad = model.flat_grads
+        opt = torch.optim.Adam([flat], lr=1e-4, betas=(0.9, 0.999), fused=True)
+    else:
+        opt, _ = build_optimizer(TRAIN_CFG, model)
     trainer = CaptionTrainer(model, opt, ex)
     feats, mask, ids = synthetic(args.batch, rank, device)
 

@@ -160,6 +160,18 @@ int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, int64_t ldl
                  int64_t label_batch_stride, int64_t pad_id, float alpha, float* loss_out, void* dlogits,
                  int64_t ld_dl, float* row_ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused Adam / AdamW step over the flat fp32 parameter buffer + bf16 shadow refresh, one launch.
+ * replaces: torch.optim.Adam(...).step() / AdamW when weight_decay != 0 (train.py:24-31,126); same
+ * arithmetic as torch's single-tensor Adam (no amsgrad).  step_dev: DEVICE int32 counter of steps
+ * already taken (read for the bias corrections, then incremented by a 1-thread kernel).
+ * shadow_bf16 may be NULL; elements [shadow_skip_begin, shadow_skip_end) get no shadow (the token
+ * embedding is gathered from the fp32 master).  n must be a multiple of 4.
+ * --------------------------------------------------------------------------------------------- */
+int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, void* stream);
+
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */
 int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -1,0 +1,67 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads without a GPU and exports every
+symbol include/vct_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "vct_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import __graft_entry__ as g
+    g.build()
+    from vct_amd import _lib
+    return _lib.LIB_PATH
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vct_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(lib_path):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    decl = declared_symbols()
+    assert len(decl) >= 17
+    missing = [s for s in decl if s not in exported]
+    assert not missing, missing
+
+
+def test_binding_covers_header(lib_path):
+    from vct_amd import _lib
+    assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
+    lib = _lib.load()
+    assert lib.vct_abi_version() == 1
+    buf = ctypes.create_string_buffer(128)
+    assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
+
+
+def test_argument_errors_are_codes_not_crashes(lib_path):
+    """Null descriptors / bad enums return VCT_E_* (negative) without touching a device."""
+    from vct_amd import _lib
+    lib = _lib.load()
+    assert lib.vct_gemm(None, None) == -1
+    d = _lib.GemmDesc()
+    assert lib.vct_gemm(d, None) == -1                      # null pointers
+    assert lib.vct_attn_fwd(None, None) == -1
+    assert lib.vct_cast(7, 0, None, None, 10, None) == -1   # bad dtype enum
+    assert lib.vct_ln_ws_rows(4864) > 0
+    with pytest.raises(ValueError):
+        _lib.check(-2, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(700, "x")
+
+
+def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):
+    from vct_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvct_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _lib.load()

@@ -237,3 +237,33 @@ def test_dropout_training_step_runs_and_varies():
     m.eval()
     l3 = float(m._forward_loss(feats, mask, ids, False)[0])
     assert abs(l3 - float(z["loss"])) < 2e-3 * float(z["loss"])   # eval mode = no dropout
+
+
+def test_fused_adam_matches_torch_adam_and_refreshes_shadow():
+    from vct_amd.trainer import FusedAdam
+    z, mc, cfg, p = _tiny()
+    m = build_model(mc, int(z["vocab"]), DEV, torch.bfloat16, p)
+    m.train()
+    feats = torch.from_numpy(z["feats"]).to(DEV); mask = torch.from_numpy(z["mask"]).to(DEV); ids = torch.from_numpy(z["ids"]).to(DEV)
+    ref_p = m.flat_params.clone().requires_grad_(True)
+    ref_opt = torch.optim.Adam([ref_p], lr=1e-3, betas=(0.9, 0.999))
+    opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.999))
+    for step in range(3):
+        m._ps.refresh_shadow()
+        m.train_step_kernels(feats, mask, ids)
+        ref_p.grad = m.flat_grads.clone()
+        ref_opt.step()
+        opt.step()
+        assert float((m.flat_params - ref_p.detach()).abs().max()) < 6e-7   # a few ulp at |w| ~ 2
+        # the bf16 shadow the GEMMs read is the rounded master (except the embedding, gathered in fp32)
+        a, b = opt.skip
+        assert torch.equal(m._ps.cflat[:a], m.flat_params[:a].to(torch.bfloat16))
+        assert torch.equal(m._ps.cflat[b:], m.flat_params[b:].to(torch.bfloat16))
+    assert int(opt.step_dev) == 3
+    # AdamW (decoupled weight decay) variant
+    m2 = build_model(mc, int(z["vocab"]), DEV, torch.float32, p)
+    r2 = m2.flat_params.clone().requires_grad_(True)
+    o2 = FusedAdam(m2, lr=1e-3, weight_decay=0.1); ro2 = torch.optim.AdamW([r2], lr=1e-3, weight_decay=0.1)
+    m2.train(); m2.train_step_kernels(feats, mask, ids)
+    r2.grad = m2.flat_grads.clone(); ro2.step(); o2.step()
+    assert float((m2.flat_params - r2.detach()).abs().max()) < 6e-7

@@ -50,11 +50,9 @@ _SIGS = {
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),
+    "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, vp]),
 }
-# entry points added by later source files (optional until those files exist in the build)
-_OPTIONAL = {
-    "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i64, i64, vp]),
-}
+_OPTIONAL = {}
 
 _lib = None
 

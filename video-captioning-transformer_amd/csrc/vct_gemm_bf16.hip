@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
   const long ldo = part ? (long)p.N : p.ldc;
   const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
   const bool lane_active = !CPL_PARTIAL || lane < 16 * CPR;
+  const bool nt_store = (size_t)p.M * (size_t)p.N * sizeof(TO) > ((size_t)64 << 20);
   float bvec[CPL][VO];
 #pragma unroll
   for (int c = 0; c < CPL; c++)
@@ -320,7 +321,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
           if (has_a) x += to_f<TO>(av.e[q]);
           ov.e[q] = from_f<TO>(x);
         }
-        *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+        if (nt_store) {
+          // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
+        } else {
+          *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+        }
         if (preact != nullptr) {
           if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
           else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
@@ -356,7 +363,6 @@ static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t s
 template <typename TO, int TA, int TB>
 static int launch_nbuf(const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st) {
   if (nbuf == 1) return launch_tiles<TO, TA, TB, 1>(p, bm, bn, grid, st);
-  if (nbuf == 3) return launch_tiles<TO, TA, TB, 3>(p, bm, bn, grid, st);
   return launch_tiles<TO, TA, TB, 2>(p, bm, bn, grid, st);
 }
 

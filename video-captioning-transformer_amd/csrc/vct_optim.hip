@@ -1,0 +1,68 @@
+// Fused Adam / AdamW over the flat fp32 parameter buffer (one launch for all 46 M parameters) that
+// also refreshes the bf16 compute shadow, so no separate cast pass is needed after the step.
+// HBM-bound: 16 B (p,g,m,v reads) + 12 B (p,m,v writes) + 2 B (shadow) per parameter.
+// Arithmetic follows torch.optim.Adam's single-tensor path (reference train.py:24-26,126):
+//   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// with bc = 1 - beta^t and t read from a DEVICE counter (the step stays hipGraph-capturable).
+#include "vct_common.h"
+
+namespace vct {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, const int32_t* __restrict__ step,
+                                                   int64_t skip_a, int64_t skip_b) {
+  const float t = (float)(step[0] + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2s = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const float decay = 1.0f - lr * wd;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float w = pp[j] * decay;
+      mp[j] = mp[j] + (1.0f - b1) * (gp[j] - mp[j]);
+      vp[j] = b2 * vp[j] + (1.0f - b2) * gp[j] * gp[j];
+      const float denom = sqrtf(vp[j]) / bc2s + eps;
+      w -= step_size * (mp[j] / denom);
+      pp[j] = w;
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    const int64_t e = i << 2;
+    if (shadow != nullptr && !(e >= skip_a && e < skip_b)) {
+      ushort4 o;
+      o.x = f2bf(pv.x); o.y = f2bf(pv.y); o.z = f2bf(pv.z); o.w = f2bf(pv.w);
+      reinterpret_cast<ushort4*>(shadow)[i] = o;
+    }
+  }
+}
+
+__global__ void bump_step_kernel(int32_t* step) { step[0] += 1; }
+
+}  // namespace vct
+using namespace vct;
+
+extern "C" int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return VCT_E_ARG;
+  if (n <= 0 || (n & 3)) return VCT_E_SHAPE;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = ((n >> 2) + 255) / 256;
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
+                     beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end);
+  VCT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}

@@ -64,6 +64,37 @@ class GradExchange:
             self.model.flat_grads.mul_(1.0 / self.world)
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW semantics (reference train.py:24-31) as ONE kernel over the model's flat
+    fp32 parameter buffer, which also rewrites the bf16 shadow the GEMMs read.  `param_groups[0]['lr']`
+    is honoured every step, so torch LR schedulers work unchanged."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        flat = torch.nn.Parameter(model.flat_params, requires_grad=True)
+        flat.grad = model.flat_grads
+        super().__init__([flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        ps = model._ps
+        self.exp_avg = torch.zeros_like(ps.flat)
+        self.exp_avg_sq = torch.zeros_like(ps.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=ps.flat.device)
+        emb = "cap_decoder.tgt_to_emb.weight"
+        a = ps.offsets[emb]
+        self.skip = (a, a + (ps.params[emb].numel() + ps.ALIGN - 1) // ps.ALIGN * ps.ALIGN)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        ps = self.model._ps
+        shadow = ps.cflat if ps.compute_dtype != torch.float32 else None
+        ops.adam_step(ps.flat, ps.gflat, self.exp_avg, self.exp_avg_sq, shadow, g["lr"], g["betas"][0], g["betas"][1],
+                      g["eps"], g["weight_decay"], self.step_dev, self.skip)
+        ps._stamp = sum(p._version for p in ps.params.values())   # shadow is current
+
+    def zero_grad(self, set_to_none: bool = True):
+        pass   # the backward schedule overwrites every gradient
+
+
 def build_optimizer(train_cfg: dict, model):
     """Optimizer + scheduler factory with the reference's config surface (train.py:20-49).  The
     optimizer sees ONE parameter -- the flat fp32 buffer, whose .grad is the flat gradient buffer --
@@ -71,15 +102,13 @@ def build_optimizer(train_cfg: dict, model):
     oc = train_cfg["optimizer"]
     flat = torch.nn.Parameter(model.flat_params, requires_grad=True)
     flat.grad = model.flat_grads
-    kw = {}
-    if flat.is_cuda:
-        kw["fused"] = True
     if oc["name"] == "adam":
-        if oc.get("weight_decay", 0) == 0:
-            opt = torch.optim.Adam([flat], lr=oc["learning_rate"], betas=tuple(oc["beta"]), **kw)
+        if flat.is_cuda:
+            opt = FusedAdam(model, lr=oc["learning_rate"], betas=tuple(oc["beta"]), weight_decay=oc.get("weight_decay", 0) or 0.0)
+        elif oc.get("weight_decay", 0) == 0:
+            opt = torch.optim.Adam([flat], lr=oc["learning_rate"], betas=tuple(oc["beta"]))
         else:
-            opt = torch.optim.AdamW([flat], lr=oc["learning_rate"], betas=tuple(oc["beta"]),
-                                    weight_decay=oc["weight_decay"], **kw)
+            opt = torch.optim.AdamW([flat], lr=oc["learning_rate"], betas=tuple(oc["beta"]), weight_decay=oc["weight_decay"])
     elif oc["name"] == "sgd":
         opt = torch.optim.SGD([flat], lr=oc["learning_rate"], momentum=oc["momentum"])
     else:
@@ -107,8 +136,11 @@ class CaptionTrainer:
     def step(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
         """Returns this rank's loss as a device tensor [1] (no host sync)."""
         m = self.model
-        m._ps.refresh_shadow(force=True)          # the optimizer wrote the fp32 masters
-        m._ps._stamp = sum(p._version for p in m._ps.params.values())
+        if not isinstance(self.opt, FusedAdam):
+            m._ps.refresh_shadow(force=True)      # a torch optimizer wrote the fp32 masters: re-cast the shadow
+            m._ps._stamp = sum(p._version for p in m._ps.params.values())
+        else:
+            m._ps.refresh_shadow()                # FusedAdam keeps the shadow current (first step: cast once)
         hook = self.ex.bucket_ready if (self.ex is not None and self.ex.world > 1) else None
         loss = m.train_step_kernels(feats, mask, ids, bucket_ready=hook)   # zero_grad is implicit: grads are overwritten
         if hook is not None:
