@@ -101,6 +101,9 @@ typedef struct vct_attn_desc {
   void* dq; int64_t ld_dq;
   void* dk; int64_t ld_dk;
   void* dv; int64_t ld_dv;
+  /* optional batch strides in ELEMENTS (0 = dense: L * ld).  A KV cache [B, Lmax, ...] read with
+   * Lk < Lmax sets k_bs = v_bs = Lmax * ld. */
+  int64_t q_bs, k_bs, v_bs, o_bs;
 } vct_attn_desc;
 int vct_attn_fwd(const vct_attn_desc* d, void* stream);
 int vct_attn_bwd(const vct_attn_desc* d, void* stream);
@@ -175,8 +178,10 @@ int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */
 int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
-/* first-index argmax per row (torch.max(dim=1) tie-break, MMT4Caption.py:165); out int64 [rows] */
-int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, void* stream);
+/* first-index argmax per row (torch.max(dim=1) tie-break, MMT4Caption.py:165); out[row * out_stride] int64
+ * (out_stride lets the decode loop write straight into column t of the id matrix ys[B, max_len]) */
+int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
+                    void* stream);
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);
 

@@ -29,7 +29,7 @@ class AttnDesc(C.Structure):
                 ("reserved", i32), ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64),
                 ("o", vp), ("ldo", i64), ("key_pad", vp), ("seed", vp), ("site", u32), ("p_drop", f32),
                 ("d_o", vp), ("ld_do", i64), ("dq", vp), ("ld_dq", i64), ("dk", vp), ("ld_dk", i64),
-                ("dv", vp), ("ld_dv", i64)]
+                ("dv", vp), ("ld_dv", i64), ("q_bs", i64), ("k_bs", i64), ("v_bs", i64), ("o_bs", i64)]
 
 
 _SIGS = {
@@ -48,7 +48,7 @@ _SIGS = {
     "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, u32, f32, vp]),
     "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
-    "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),
     "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, vp]),
 }

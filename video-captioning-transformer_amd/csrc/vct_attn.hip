@@ -28,6 +28,7 @@ struct AttnP {
   void* dq; long ld_dq;
   void* dk; long ld_dk;
   void* dv; long ld_dv;
+  long q_bs, k_bs, v_bs, o_bs;
 };
 
 template <typename T, int DT> struct AttnCfg {
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
   T* Qs = reinterpret_cast<T*>(smem);
   T* Ks = Qs + RQ * C::STR;
   T* Vs = Ks + RK * C::STR;
-  const T* qg = reinterpret_cast<const T*>(p.q) + (long)b * p.Lq * p.ldq + (long)h * p.hd;
-  const T* kg = reinterpret_cast<const T*>(p.k) + (long)b * p.Lk * p.ldk + (long)h * p.hd;
-  const T* vg = reinterpret_cast<const T*>(p.v) + (long)b * p.Lk * p.ldv + (long)h * p.hd;
-  T* og = reinterpret_cast<T*>(p.o) + (long)b * p.Lq * p.ldo + (long)h * p.hd;
+  const T* qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + (long)h * p.hd;
+  const T* kg = reinterpret_cast<const T*>(p.k) + (long)b * p.k_bs + (long)h * p.hd;
+  const T* vg = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)h * p.hd;
+  T* og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)h * p.hd;
   stage_rows<T, DT>(Qs, qg, p.ldq, p.Lq, p.hd, RQ, lane);
   stage_rows<T, DT>(Ks, kg, p.ldk, p.Lk, p.hd, RK, lane);
   stage_rows<T, DT>(Vs, vg, p.ldv, p.Lk, p.hd, RK, lane);
@@ -463,6 +464,11 @@ static int attn_common(const vct_attn_desc* d, bool bwd, void* stream) {
   p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
   p.d_o = d->d_o; p.ld_do = d->ld_do;
   p.dq = d->dq; p.ld_dq = d->ld_dq; p.dk = d->dk; p.ld_dk = d->ld_dk; p.dv = d->dv; p.ld_dv = d->ld_dv;
+  p.q_bs = d->q_bs ? d->q_bs : (long)d->Lq * d->ldq;
+  p.k_bs = d->k_bs ? d->k_bs : (long)d->Lk * d->ldk;
+  p.v_bs = d->v_bs ? d->v_bs : (long)d->Lk * d->ldv;
+  p.o_bs = d->o_bs ? d->o_bs : (long)d->Lq * d->ldo;
+  if (bwd && (d->q_bs || d->k_bs || d->v_bs || d->o_bs)) return VCT_E_ARG;  // strided batches: forward (decode) only
   hipStream_t st = (hipStream_t)stream;
   return d->dtype == VCT_BF16 ? attn_dispatch<bf16_t>(p, bwd, st) : attn_dispatch<float>(p, bwd, st);
 }

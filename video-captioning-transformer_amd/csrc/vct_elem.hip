@@ -295,7 +295,7 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
 
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __restrict__ x, int64_t ldx,
-                                                          int64_t* __restrict__ out) {
+                                                          int64_t* __restrict__ out, int64_t out_stride) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   const T* r = x + (size_t)blockIdx.x * ldx;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __r
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; w++)
       if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
-    out[blockIdx.x] = (bi == 0x7fffffff) ? 0 : bi;
+    out[(size_t)blockIdx.x * out_stride] = (bi == 0x7fffffff) ? 0 : bi;
   }
 }
 
@@ -451,14 +451,15 @@ extern "C" int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst
   return VCT_OK;
 }
 
-extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, void* stream) {
+extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
+                               void* stream) {
   if (!dt_ok(dtype) || !x || !out) return VCT_E_ARG;
-  if (rows <= 0 || cols <= 0) return VCT_E_SHAPE;
+  if (rows <= 0 || cols <= 0 || out_stride <= 0) return VCT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out);
+    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride);
   else
-    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out);
+    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

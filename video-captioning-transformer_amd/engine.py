@@ -398,3 +398,80 @@ class DecoderEngine(_StackBase):
         if bucket_ready is not None:
             bucket_ready(2)
         return dmem
+
+
+class DecodeState:
+    """Static buffers of one greedy-decode session (B, Te, Lmax): id matrix, per-layer self-attention KV
+    cache [B, Lmax, 2d], per-layer cross-attention K/V of the memory (computed once), step temporaries
+    and the hipGraphs of the per-token step (one per position; every kernel argument is baked)."""
+
+    def __init__(self, eng: "DecoderEngine", Bn: int, Te: int, Lmax: int):
+        d, L, dt, dev = eng.cfg["d"], eng.cfg["layers"], eng.dt, eng.dev
+        self.B, self.Te, self.Lmax = Bn, Te, Lmax
+        self.ys = torch.zeros(Bn, Lmax, dtype=torch.long, device=dev)
+        self.ended = torch.zeros(Bn, dtype=torch.bool, device=dev)
+        self.all_ended_at = torch.full((1,), Lmax, dtype=torch.long, device=dev)   # first t at which every row had ended
+        self.kv_self = [torch.zeros(Bn * Lmax, 2 * d, dtype=dt, device=dev) for _ in range(L)]
+        self.kv_cross = [torch.empty(Bn * Te, 2 * d, dtype=dt, device=dev) for _ in range(L)]
+        self.b = _Buf(dev)
+        self.graphs = {}
+
+
+def _decoder_decode_begin(self, st: DecodeState, mem: torch.Tensor, start_id: int, pad_id: int):
+    """Encoder memory -> cross-attention K/V of every layer (once per decode); reset ids / cache."""
+    d = self.cfg["d"]
+    st.ys.fill_(pad_id)
+    st.ys[:, 0] = start_id
+    st.ended.zero_()
+    st.all_ended_at.fill_(st.Lmax)
+    for l in range(self.cfg["layers"]):
+        lp = f"decoder.layers.{l}.multihead_attn."
+        ops.gemm(mem, self.W(lp + "in_proj_weight")[d:], st.kv_cross[l], bias=self.F(lp + "in_proj_bias")[d:])
+
+
+def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
+    """One greedy step with the KV cache: consumes token ys[:, t-1], writes ys[:, t].  Equivalent to
+    CapDecoder.decode_word on ys[:, :t] + torch.max (CapDecoder.py:62-79, MMT4Caption.py:164-172): the
+    keys/values of positions < t-1 are the cached projections of the same inputs."""
+    d, H, L, Bn, Te, Lmax = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax
+    b = st.b
+    self.p_drop = 0.0
+    pos_row = self.pos[t - 1:t]                       # positional row of the consumed token
+    x = ops.embed_fwd(st.ys[:, t - 1:t], 1, self.F("tgt_to_emb.weight"), pos_row, b.get("x0", (Bn, d), self.dt))
+    for l in range(L):
+        lp, tag = f"decoder.layers.{l}.", f"L{l}."
+        sa = lp + "self_attn."
+        q = b.get(tag + "q", (Bn, d), self.dt)
+        ops.gemm(x, self.W(sa + "in_proj_weight")[:d], q, bias=self.F(sa + "in_proj_bias")[:d])
+        kv_new = st.kv_self[l].view(Bn, Lmax, 2 * d)[:, t - 1, :]          # [B, 2d] view, row stride Lmax*2d
+        ops.gemm(x, self.W(sa + "in_proj_weight")[d:], kv_new, bias=self.F(sa + "in_proj_bias")[d:])
+        o = b.get(tag + "o", (Bn, d), self.dt)
+        ops.attn_fwd(q, st.kv_self[l][:, :d], st.kv_self[l][:, d:], o, Bn, H, 1, t, kv_batch_stride=Lmax * 2 * d)
+        a = b.get(tag + "a", (Bn, d), self.dt)
+        ops.gemm(o, self.W(sa + "out_proj.weight"), a, bias=self.F(sa + "out_proj.bias"))
+        x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, None)
+        ca = lp + "multihead_attn."
+        qc = b.get(tag + "qc", (Bn, d), self.dt)
+        ops.gemm(x1, self.W(ca + "in_proj_weight")[:d], qc, bias=self.F(ca + "in_proj_bias")[:d])
+        oc = b.get(tag + "oc", (Bn, d), self.dt)
+        ops.attn_fwd(qc, st.kv_cross[l][:, :d], st.kv_cross[l][:, d:], oc, Bn, H, 1, Te)
+        c = b.get(tag + "c", (Bn, d), self.dt)
+        ops.gemm(oc, self.W(ca + "out_proj.weight"), c, bias=self.F(ca + "out_proj.bias"))
+        x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, None)
+        h = b.get(tag + "h", (Bn, self.cfg["ff"]), self.dt)
+        ops.gemm(x2, self.W(lp + "linear1.weight"), h, bias=self.F(lp + "linear1.bias"), act=self.cfg["activation"])
+        f = b.get(tag + "f", (Bn, d), self.dt)
+        ops.gemm(h, self.W(lp + "linear2.weight"), f, bias=self.F(lp + "linear2.bias"))
+        x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, None)
+    y = self._ln_fwd(b, "nf.", "decoder.norm.", x, None, None)
+    logits = b.get("logits", (Bn, self.Vp), self.dt)
+    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
+    ops.argmax_rows(logits, st.ys[:, t], cols=self.V)
+    # sticky end flags + the first step at which every row has ended (device side, no host sync)
+    st.ended |= st.ys[:, t] == end_id
+    done = st.ended.all()
+    st.all_ended_at.copy_(torch.where(done & (st.all_ended_at == Lmax), torch.full_like(st.all_ended_at, t), st.all_ended_at))
+
+
+DecoderEngine.decode_begin = _decoder_decode_begin
+DecoderEngine.decode_step = _decoder_decode_step

@@ -173,13 +173,18 @@ class MMT4Caption(nn.Module):
         return result
 
     @torch.no_grad()
-    def greedy_decode_ids(self, video_feat, video_masks=None, max_len: int = 30) -> torch.Tensor:
-        """The id matrix ys [B, <=max_len] of MMT4Caption.greedy_decode (MMT4Caption.py:159-172)."""
+    def greedy_decode_ids(self, video_feat, video_masks=None, max_len: int = 30, kv_cache: bool = True,
+                          use_graphs: bool = True) -> torch.Tensor:
+        """The id matrix ys [B, <=max_len] of MMT4Caption.greedy_decode (MMT4Caption.py:159-172).
+        kv_cache=False runs the reference's O(L^2) algorithm (full decoder re-run per token)."""
         was_training = self.training
         self.eval()
         try:
             from .. import decode
-            return decode.greedy_decode_ids(self, video_feat[0], video_masks[0] if video_masks is not None else None, max_len)
+            mask = video_masks[0] if video_masks is not None else None
+            if kv_cache:
+                return decode.greedy_decode_ids(self, video_feat[0], mask, max_len, use_graphs=use_graphs)
+            return decode.greedy_decode_ids_reference_algorithm(self, video_feat[0], mask, max_len)
         finally:
             self.train(was_training)
 

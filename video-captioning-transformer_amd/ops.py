@@ -93,11 +93,13 @@ def _attn_desc(dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout):
     return d
 
 
-def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
-    """q:[B*Lq, >=H*hd] views (any row stride), k,v:[B*Lk, ..]; o:[B*Lq, H*hd].  key_pad: uint8 [B,Lk]."""
+def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None, kv_batch_stride: int = 0):
+    """q:[B*Lq, >=H*hd] views (any row stride), k,v:[B*Lk, ..]; o:[B*Lq, H*hd].  key_pad: uint8 [B,Lk].
+    kv_batch_stride (elements): K/V live in a cache [B, Lmax, ...] and only the first Lk rows of each batch are read."""
     hd = o.shape[1] // H
     d = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
     d.o, d.ldo = o.data_ptr(), _ld(o)
+    d.k_bs = d.v_bs = kv_batch_stride
     L.check(L.load().vct_attn_fwd(d, L.stream_ptr()), "vct_attn_fwd")
     return o
 
@@ -179,8 +181,9 @@ def cast(src, dst):
 
 
 def argmax_rows(x, out, cols=None):
+    """out: int64 1-D tensor (any stride): out[row] = first index of the row maximum."""
     L.check(L.load().vct_argmax_rows(L.dtype_code(x.dtype), x.shape[0], cols or x.shape[1], x.data_ptr(), _ld(x),
-                                     out.data_ptr(), L.stream_ptr()), "vct_argmax_rows")
+                                     out.data_ptr(), out.stride(0), L.stream_ptr()), "vct_argmax_rows")
     return out
 
 
