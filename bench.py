@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce payload")
+    ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
     args = ap.parse_args()
 
@@ -116,7 +117,11 @@ def main():
     model = MMT4Caption(MODEL_CFG, device=device, compute_dtype={"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype])
     model.mode("caption")
     model.train()
-    ex = GradExchange(model, payload_dtype=torch.bfloat16 if args.payload == "bf16" else None) if world > 1 else None
+    if args.force_exchange and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    ex = (GradExchange(model, payload_dtype=torch.bfloat16 if args.payload == "bf16" else None, force=args.force_exchange)
+          if (world > 1 or args.force_exchange) else None)
     if args.torch_adam:
         flat = torch.nn.Parameter(model.flat_params); flat.grad = model.flat_grads
         opt = torch.optim.Adam([flat], lr=1e-4, betas=(0.9, 0.999), fused=True)
@@ -177,7 +182,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

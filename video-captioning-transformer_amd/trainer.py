@@ -23,9 +23,11 @@ class GradExchange:
     * payload: fp32 by default; `payload_dtype=torch.bfloat16` halves the xGMI bytes (cast kernels
       from libvct_hip.so on both sides)."""
 
-    def __init__(self, model, group=None, payload_dtype: Optional[torch.dtype] = None, broadcast: bool = True):
+    def __init__(self, model, group=None, payload_dtype: Optional[torch.dtype] = None, broadcast: bool = True,
+                 force: bool = False):
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: run the collectives even alone
         self.buckets = model.grad_buckets()
         self.payload_dtype = payload_dtype
         self._work: List = []
@@ -33,12 +35,12 @@ class GradExchange:
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"   # RCCL has ReduceOp.AVG; gloo does not
         if payload_dtype is not None and payload_dtype != torch.float32:
             self._stage = torch.empty(model.flat_grads.numel(), dtype=payload_dtype, device=model.flat_grads.device)
-        if broadcast and self.world > 1:
+        if broadcast and self.active:
             dist.broadcast(model.flat_params, src=0, group=group)
             model._ps.refresh_shadow(force=True)
 
     def bucket_ready(self, i: int):
-        if self.world == 1:
+        if not self.active:
             return
         a, b = self.buckets[i]
         if b <= a:
@@ -52,7 +54,7 @@ class GradExchange:
         self._work.append((dist.all_reduce(g, op=op, group=self.group, async_op=True), i))
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         for w, i in self._work:
             w.wait()
@@ -141,7 +143,7 @@ class CaptionTrainer:
             m._ps._stamp = sum(p._version for p in m._ps.params.values())
         else:
             m._ps.refresh_shadow()                # FusedAdam keeps the shadow current (first step: cast once)
-        hook = self.ex.bucket_ready if (self.ex is not None and self.ex.world > 1) else None
+        hook = self.ex.bucket_ready if (self.ex is not None and self.ex.active) else None
         loss = m.train_step_kernels(feats, mask, ids, bucket_ready=hook)   # zero_grad is implicit: grads are overwritten
         if hook is not None:
             self.ex.finish()
