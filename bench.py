@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce payload")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (N=1); the per-kernel roofline "
+                    "timing then comes from an eager tail pass, so the default is eager launches")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
     args = ap.parse_args()
@@ -127,7 +129,7 @@ def main():
         opt = torch.optim.Adam([flat], lr=1e-4, betas=(0.9, 0.999), fused=True)
     else:
         opt, _ = build_optimizer(TRAIN_CFG, model)
-    trainer = CaptionTrainer(model, opt, ex)
+    trainer = CaptionTrainer(model, opt, ex, use_graph=args.graph)
     feats, mask, ids = synthetic(args.batch, rank, device)
 
     def sync():
@@ -145,6 +147,12 @@ def main():
         loss = trainer.step(feats, mask, ids)
     sync()
     elapsed = time.perf_counter() - t0
+    if trainer.use_graph:      # replayed graphs bypass the Python taps: time the generator GEMMs in an eager tail pass
+        trainer.use_graph = False
+        for _ in range(5):
+            trainer.step(feats, mask, ids)
+        torch.cuda.synchronize()
+        trainer.use_graph = True
     taps = {k: list(v) for k, v in ops.event_taps.items()}
     ops.event_taps.clear()
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -168,7 +176,8 @@ def main():
             "config": {"workload": "configs[1]: 2 enc + 2 dec layers d=512 ff=2048 H=8 V=30522, synthetic (256,12,512) "
                                    "features -> 20-token captions per GPU, fwd+bwd+Adam, dropout 0.3, SCE alpha 0.5",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S_TOK, "frames": T_FRAMES,
-                       "parallelism": f"dp{world}", "grad_allreduce_payload": args.payload if world > 1 else None},
+                       "parallelism": f"dp{world}", "grad_allreduce_payload": args.payload if world > 1 else None,
+                       "hipgraph_step": bool(trainer.use_graph)},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),
             "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd (vct_gemm NT, 128x128 tiles)",

@@ -313,3 +313,23 @@ def test_tiny_decode_stop_rule_with_kv_cache():
         for graphs in (False, True):
             ys = m.greedy_decode_ids([feats], None, max_len=12, kv_cache=True, use_graphs=graphs)
             assert np.array_equal(ys.cpu().numpy(), z[f"{tag}/ys"]), (tag, graphs)
+
+
+def test_graph_captured_train_step_matches_eager():
+    """The hipGraph-replayed step (fwd+bwd+Adam+seed advance) is bitwise the eager step, dropout active."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    z, mc, cfg, p = _tiny()
+    mc = dict(mc); mc["dropout"] = 0.3
+    feats = torch.from_numpy(z["feats"]).to(DEV); mask = torch.from_numpy(z["mask"]).to(DEV); ids = torch.from_numpy(z["ids"]).to(DEV)
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(5)
+        m = build_model(mc, int(z["vocab"]), DEV, torch.bfloat16, p)
+        m.train()
+        tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), use_graph=use_graph)
+        losses = [float(tr.step(feats, mask, ids)) for _ in range(6)]
+        assert tr.use_graph == use_graph
+        outs.append((losses, m.flat_params.clone(), int(m._seed)))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    assert outs[0][0][-1] < outs[0][0][0]      # and it learns

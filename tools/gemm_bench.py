@@ -62,9 +62,9 @@ if __name__ == "__main__":
     for s in SHAPES:
         if sel and not any(x in s[0] for x in sel):
             continue
-        for nbuf in (1, 2, 3):
+        for nbuf in (1, 2):
             row = []
-            for tile in range(1, 5):
+            for tile in (1, 2, 3, 4):
                 ms, tf = run(*s, tile + 10 * nbuf)
                 row.append(f"{ms*1e3:7.1f}us {tf:4.0f}TF")
             print(f"{s[0]:30s} {nbuf:4d} " + " ".join(f"{r:>15s}" for r in row), flush=True)

@@ -1,0 +1,378 @@
+// bf16 MFMA GEMM, second generation, for gfx950 (the throughput path; fp32 parity mode stays in
+// vct_gemm.hip).   C[M,N] = epilogue(op(A)[M,K] * op(B)[K,N]),  v_mfma_f32_16x16x32_bf16.
+//
+//  * operands go HBM -> LDS directly (global_load_lds_dwordx4: 16 B per lane, no VGPR round trip),
+//    double-buffered, ONE barrier per 64-deep K tile; the next tile's DMA flies under the MFMAs.
+//  * LDS images are unpadded and lane-linear (what the DMA requires); bank conflicts are removed
+//    by XOR-swizzling the per-lane SOURCE address and applying the same involution on the read:
+//      K-contiguous operand : [rows][64] bf16 (128-B rows), 16-B chunk c of row r sits at c ^ (r & 7),
+//                             fragments by ds_read_b128;
+//      M/N-contiguous operand: [64 k][cols] bf16, 32-B block b of k-row r sits at b ^ (r & (NB-1)),
+//                             fragments by the LDS transpose read ds_read_b64_tr_b16 (no transposed
+//                             copies in HBM for dX = dY W and dW = dY^T X).
+//  * rows beyond M/N are CLAMPED (their garbage only reaches outputs that are never stored); a
+//    ragged last K tile goes through a zero-filling register path into the same swizzled image.
+//  * workgroup -> tile map is XCD-aware: each XCD (private 4 MB L2) owns a contiguous run of tiles,
+//    walked fastest along the dimension with fewer tiles so the smaller operand stays L2-resident
+//    and the larger one streams once.
+//  * epilogue: per-wave fp32 LDS transpose so every lane stores 16 contiguous bytes; bias /
+//    activation (+ saved pre-activation) / dropout / residual-gradient accumulate / activation
+//    derivative fused; bias gradient via one extra MFMA against a ones fragment; deterministic
+//    split-K (partials + second pass in vct_gemm.hip).
+#pragma once
+#include "vct_common.h"
+#include "vct_gemm_params.h"
+
+namespace vct {
+
+constexpr int BK2 = 64;
+
+// ---- LDS image addressing (bytes) --------------------------------------------------------------
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+template <int R> __device__ __forceinline__ int mc_off(int krow, int col) {  // col in elements, multiple of 4
+  constexpr int NB = R / 16;  // 32-byte blocks per k-row
+  const int b = col >> 4;
+  return krow * (R * 2) + (((b ^ (krow & (NB - 1))) << 5) | ((col & 15) << 1));
+}
+
+// issue the DMA of one operand tile (full K tile, rows clamped)
+template <bool MC, int R>
+__device__ __forceinline__ void dma_tile(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext,
+                                         int k0, int wave, int lane) {
+  constexpr int NI = R * 8 / 256;  // wave-instructions per wave (1 KiB each)
+#pragma unroll
+  for (int q = 0; q < NI; q++) {
+    const int ci = q * 4 + wave;  // 1-KiB chunk index
+    const bf16_t* src;
+    if constexpr (!MC) {
+      const int row = ci * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      const int gr = min(r0 + row, r_ext - 1);
+      src = base + (long)gr * ld + k0 + c * 8;
+    } else {
+      constexpr int CPRW = R / 8;         // 16-byte chunks per k-row
+      constexpr int RPI = 64 / CPRW;      // k-rows per wave-instruction
+      constexpr int NB = R / 16;
+      const int krow = ci * RPI + lane / CPRW;
+      const int p = lane % CPRW;
+      const int b = (p >> 1) ^ (krow & (NB - 1));
+      const int col = (b * 2 + (p & 1)) * 8;
+      const int rlim = ((r_ext + 7) & ~7) - 8;  // last fully readable vector (ld covers the rounded-up extent)
+      const int gc = min(r0 + col, rlim);
+      src = base + (long)(k0 + krow) * ld + gc;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
+  }
+}
+
+// ragged last K tile: predicated 16-byte loads (zero fill) written into the same swizzled image
+struct alignas(16) V16b { uint32_t w[4]; };
+template <bool MC, int R>
+__device__ __forceinline__ void tail_tile(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext,
+                                          int k0, int K, int tid) {
+  constexpr int NV = R * 8 / 256;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int v = tid + i * 256;
+    V16b val; val.w[0] = val.w[1] = val.w[2] = val.w[3] = 0u;
+    if constexpr (!MC) {
+      const int row = v >> 3, c = v & 7;
+      const int gr = r0 + row, gk = k0 + c * 8;
+      if (gr < r_ext && gk < K) val = *reinterpret_cast<const V16b*>(base + (long)gr * ld + gk);
+      *reinterpret_cast<V16b*>(lds + kc_off(row, c)) = val;
+    } else {
+      constexpr int CPRW = R / 8;
+      const int krow = v / CPRW, col = (v % CPRW) * 8;
+      const int gk = k0 + krow, gr = r0 + col;
+      if (gk < K && gr < r_ext) val = *reinterpret_cast<const V16b*>(base + (long)gk * ld + gr);
+      *reinterpret_cast<V16b*>(lds + mc_off<R>(krow, col)) = val;
+    }
+  }
+}
+
+template <bool MC, int R, bool KSPLIT>
+__device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, int ks, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  if constexpr (!MC) {
+    return *reinterpret_cast<const bf16x8*>(lds + kc_off(r_base + i, ks * 4 + g));
+  } else {
+    const int kb1 = ks * 32 + (KSPLIT ? g * 4 : g * 8);
+    const int kb2 = KSPLIT ? ks * 32 + 16 + g * 4 : kb1 + 4;
+    const int col = r_base + (i & 3) * 4;
+    const s16x4 lo = lds_tr16(reinterpret_cast<const bf16_t*>(lds + mc_off<R>(kb1 + (i >> 2), col)));
+    const s16x4 hi = lds_tr16(reinterpret_cast<const bf16_t*>(lds + mc_off<R>(kb2 + (i >> 2), col)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <typename TO, int TA, int TB, int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
+  constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
+  constexpr bool KSPLIT = A_MC && B_MC;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int STG_STRIDE = WN + 4;
+  constexpr int STG_BYTES = 4 * 16 * STG_STRIDE * 4;
+  constexpr int NDMA = BM / 32 + BN / 32;               // DMA instructions per K tile per wave
+  static_assert(NBUF * BUF_BYTES >= STG_BYTES, "staging must fit");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[NBUF * BUF_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile map (bijective for any tile count)
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wgid;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  // Within an XCD's run, tiles are walked in groups of GRP along the LONGER tile dimension: the GRP
+  // tiles' operand slabs stay L2-resident while the shorter dimension is swept, so each operand
+  // element is fetched from HBM/MALL once per group instead of once per tile.
+  constexpr int GRP = 8;
+  int tile_m, tile_n;
+  {
+    const bool n_long = p.tiles_n >= p.tiles_m;
+    const int tl = n_long ? p.tiles_n : p.tiles_m, ts = n_long ? p.tiles_m : p.tiles_n;
+    const int per_group = GRP * ts;
+    const int grp = wgid / per_group, rem = wgid - grp * per_group;
+    const int gsz = min(GRP, tl - grp * GRP);           // last group may be short
+    const int tshort = rem / gsz, tlong = grp * GRP + rem % gsz;
+    tile_m = n_long ? tshort : tlong;
+    tile_n = n_long ? tlong : tshort;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nkt = (p.K + BK2 - 1) / BK2;
+  const int kt_begin = blockIdx.z * p.kt_per_split;
+  const int kt_end = min(nkt, kt_begin + p.kt_per_split);
+  const int kt_full_end = min(kt_end, p.K / BK2);   // tiles fully inside K go by DMA
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x4 acc[TM][TN];
+  f32x4 accb[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+  }
+  const bool do_bias_grad = (p.bias_grad != nullptr) && (tile_n == 0) && (wn == 0);
+  const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+  auto compute = [&](const unsigned char* la, const unsigned char* lb) {
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 32; ks++) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) fa[i] = frag2<A_MC, BM, KSPLIT>(la, wm * WM + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; j++) fb[j] = frag2<B_MC, BN, KSPLIT>(lb, wn * WN + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_bias_grad) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+  };
+
+  // stage K tile `kt` into buffer `buf`: DMA when the tile lies fully inside K, else the zero-filling
+  // register path (at most one ragged tile per GEMM, always the last)
+  auto stage = [&](int kt, int buf) {
+    unsigned char* nb = lds_raw + buf * BUF_BYTES;
+    if (kt < kt_full_end) {
+      dma_tile<A_MC, BM>(nb, A, p.lda, m0, p.M, kt * BK2, wave, lane);
+      dma_tile<B_MC, BN>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, wave, lane);
+    } else {
+      tail_tile<A_MC, BM>(nb, A, p.lda, m0, p.M, kt * BK2, p.K, tid);
+      tail_tile<B_MC, BN>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, p.K, tid);
+    }
+  };
+  // NBUF = 1: stage -> wait -> barrier -> compute -> barrier (smallest LDS, most workgroups per CU)
+  // NBUF = 2: next tile's DMA flies under the MFMAs, one barrier per tile
+  // NBUF = 3: two tiles in flight, counted vmcnt + raw s_barrier (the DMA queue is never drained)
+  if constexpr (NBUF == 1) {
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+      if (kt > kt_begin) __syncthreads();             // everyone finished reading the buffer
+      stage(kt, 0);
+      __syncthreads();                                // DMA landed (vmcnt(0)) for everyone
+      compute(lds_raw, lds_raw + A_BYTES);
+    }
+  } else if constexpr (NBUF == 2) {
+    if (kt_begin < kt_end) stage(kt_begin, 0);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+      __syncthreads();
+      if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+      compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES);
+      cur ^= 1;
+    }
+  } else {
+    if (kt_begin < kt_end) stage(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+      if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+      compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  }
+
+  // ---- epilogue (see vct_gemm.hip for the rationale of the per-wave LDS transpose) ---------------
+  const int c16 = lane & 15, g4 = (lane >> 4) * 4;
+  if (do_bias_grad && c16 == 0) {
+    float* bg = p.partial != nullptr ? p.bias_partial + (size_t)blockIdx.z * p.M : p.bias_grad;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * WM + i * 16 + g4 + r;
+        if (row < p.M) bg[row] = accb[i][r];
+      }
+  }
+  __syncthreads();
+  float* stg = reinterpret_cast<float*>(lds_raw) + wave * 16 * STG_STRIDE;
+  const bool part = p.partial != nullptr;
+  constexpr int VO = 16 / (int)sizeof(TO);
+  constexpr int CPR = WN / VO;
+  constexpr int CPL = (16 * CPR + 63) / 64;
+  constexpr bool CPL_PARTIAL = (16 * CPR) < 64;   // fewer chunks than lanes (narrow wave tile)
+  const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
+  TO* C = reinterpret_cast<TO*>(p.C);
+  TO* preact = reinterpret_cast<TO*>(p.preact);
+  const TO* addend = reinterpret_cast<const TO*>(p.addend);
+  const TO* dact = reinterpret_cast<const TO*>(p.dact);
+  float* partC = part ? p.partial + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : nullptr;
+  const long ldo = part ? (long)p.N : p.ldc;
+  const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
+  const bool lane_active = !CPL_PARTIAL || lane < 16 * CPR;
+  const bool nt_store = (size_t)p.M * (size_t)p.N * sizeof(TO) > ((size_t)64 << 20);
+  float bvec[CPL][VO];
+#pragma unroll
+  for (int c = 0; c < CPL; c++)
+#pragma unroll
+    for (int q = 0; q < VO; q++) bvec[c][q] = 0.0f;
+  if (p.bias != nullptr && !part) {
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int col = n0 + wn * WN + ((c * 64 + lane) % CPR) * VO;
+#pragma unroll
+      for (int q = 0; q < VO; q++) bvec[c][q] = p.bias[min(col + q, p.N - 1)];
+    }
+  }
+  struct alignas(16) OutV { TO e[VO]; };
+  static_for<TM>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    static_for<TN>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+#pragma unroll
+      for (int r = 0; r < 4; r++) stg[(g4 + r) * STG_STRIDE + j * 16 + c16] = acc[i][j][r];
+    });
+    static_for<CPL>([&](auto CI) {
+      constexpr int c = decltype(CI)::value;
+      const int chunk = c * 64 + lane;
+      const int rr = (chunk / CPR) & 15, cc = (chunk % CPR) * VO;
+      const int row = m0 + wm * WM + i * 16 + rr, col = n0 + wn * WN + cc;
+      float v[VO];
+#pragma unroll
+      for (int q = 0; q < VO; q += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stg + rr * STG_STRIDE + cc + q);
+        v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+      }
+      if (!lane_active || row >= p.M || col >= p.N) return;
+      const bool full = vec_ok && (col + VO <= p.N);
+      if (part) {
+        float* dst = partC + (size_t)row * p.N + col;
+        if (full) {
+#pragma unroll
+          for (int q = 0; q < VO; q += 4) *reinterpret_cast<f32x4*>(dst + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+        } else {
+          for (int q = 0; q < VO; q++) if (col + q < p.N) dst[q] = v[q];
+        }
+        return;
+      }
+      if (full) {
+        OutV dv, av, ov, pv;
+        const bool has_d = dact != nullptr, has_a = addend != nullptr;
+        if (has_d) dv = *reinterpret_cast<const OutV*>(dact + (size_t)row * p.ld_dact + col);
+        if (has_a) av = *reinterpret_cast<const OutV*>(addend + (size_t)row * p.ld_addend + col);
+#pragma unroll
+        for (int q = 0; q < VO; q++) {
+          float x = v[q] + bvec[c][q];
+          pv.e[q] = from_f<TO>(x);
+          x = act_f(p.act, x);
+          if (has_d) x *= dact_f(p.dact_kind, to_f<TO>(dv.e[q]));
+          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+          if (has_a) x += to_f<TO>(av.e[q]);
+          ov.e[q] = from_f<TO>(x);
+        }
+        if (nt_store) {
+          // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
+        } else {
+          *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+        }
+        if (preact != nullptr) {
+          if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
+          else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
+        }
+      } else {
+        for (int q = 0; q < VO; q++) {
+          if (col + q >= p.N) break;
+          float x = v[q] + bvec[c][q];
+          if (preact != nullptr) preact[(size_t)row * p.ld_preact + col + q] = from_f<TO>(x);
+          x = act_f(p.act, x);
+          if (dact != nullptr) x *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
+          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+          if (addend != nullptr) x += to_f<TO>(addend[(size_t)row * p.ld_addend + col + q]);
+          C[(size_t)row * p.ldc + col + q] = from_f<TO>(x);
+        }
+      }
+    });
+  });
+}
+
+template <typename TO, int TA, int TB, int NBUF>
+static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t st) {
+#define VCT_LAUNCH(BM_, BN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
+  if (bm == 128 && bn == 128) VCT_LAUNCH(128, 128);
+  else if (bm == 128 && bn == 64) VCT_LAUNCH(128, 64);
+  else if (bm == 64 && bn == 128) VCT_LAUNCH(64, 128);
+  else if (bm == 64 && bn == 64) VCT_LAUNCH(64, 64);
+  else return VCT_E_SHAPE;
+#undef VCT_LAUNCH
+  return VCT_OK;
+}
+
+template <typename TO, int TA, int TB>
+static int launch_nbuf(const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st) {
+  if (nbuf == 1) return launch_tiles<TO, TA, TB, 1>(p, bm, bn, grid, st);
+  return launch_tiles<TO, TA, TB, 2>(p, bm, bn, grid, st);
+}
+
+
+// one translation unit per operand layout (parallel builds): see vct_gemm_bf16_{nt,nn,tn}.hip
+template <int TA, int TB>
+static int gemm_bf16_v2_layout(const vct_gemm_desc* d, const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st) {
+  return d->out_dtype == VCT_BF16 ? launch_nbuf<bf16_t, TA, TB>(p, bm, bn, nbuf, grid, st)
+                                  : launch_nbuf<float, TA, TB>(p, bm, bn, nbuf, grid, st);
+}
+
+}  // namespace vct

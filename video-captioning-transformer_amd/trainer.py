@@ -129,14 +129,20 @@ def build_optimizer(train_cfg: dict, model):
 
 class CaptionTrainer:
     """One object = the reference's `model(...) -> zero_grad -> backward -> step` loop body
-    (train.py:123-126) on the kernel fast path, with the gradient exchange folded into backward."""
+    (train.py:123-126) on the kernel fast path, with the gradient exchange folded into backward.
 
-    def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None):
+    use_graph=True (single-GPU, FusedAdam): the whole step -- forward, backward, Adam, dropout-seed
+    advance, ~190 kernel launches -- is captured once per input shape into a hipGraph and replayed;
+    inputs are copied into static buffers, the dropout seed and the Adam step counter live in device
+    memory so every replay sees fresh values."""
+
+    def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None, use_graph: bool = False):
         self.model, self.opt, self.ex = model, optimizer, exchange
         model._unit_loss_grad = True
+        self.use_graph = bool(use_graph) and (exchange is None or not exchange.active) and isinstance(optimizer, FusedAdam)
+        self._graphs = {}
 
-    def step(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
-        """Returns this rank's loss as a device tensor [1] (no host sync)."""
+    def _step_kernels(self, feats, mask, ids):
         m = self.model
         if not isinstance(self.opt, FusedAdam):
             m._ps.refresh_shadow(force=True)      # a torch optimizer wrote the fp32 masters: re-cast the shadow
@@ -150,6 +156,35 @@ class CaptionTrainer:
         self.opt.step()
         if m.training and m.video_encoder.cfg["dropout"] > 0:
             ops.advance_seed(m._seed)
+        return loss
+
+    def step(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
+        """Returns this rank's loss as a device tensor [1] (no host sync)."""
+        if not self.use_graph:
+            return self._step_kernels(feats, mask, ids)
+        key = (tuple(feats.shape), None if mask is None else tuple(mask.shape), tuple(ids.shape), self.model.training)
+        g = self._graphs.get(key)
+        if g is None:
+            # first step of this shape: run it eagerly on static copies (allocates every buffer), then record
+            # the same schedule (stream capture executes nothing); later calls replay the recording
+            static = (feats.clone(), None if mask is None else mask.clone(), ids.clone())
+            eager_loss = self._step_kernels(*static).clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    loss = self._step_kernels(*static)
+            except Exception:                       # capture is an optimisation, never a requirement
+                self.use_graph = False
+                return eager_loss
+            self._graphs[key] = (graph, static, loss)
+            return eager_loss
+        graph, static, loss = g
+        static[0].copy_(feats, non_blocking=True)
+        if mask is not None:
+            static[1].copy_(mask, non_blocking=True)
+        static[2].copy_(ids, non_blocking=True)
+        graph.replay()
         return loss
 
 
