@@ -142,16 +142,19 @@ int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* dz, void* d
  * ids: int64 [N] read with element stride id_stride from ids + b*id_batch_stride (so the token-shift
  * view tgt[:, :-1] needs no copy): token n = (b = n / S, s = n % S) -> ids[b*id_batch_stride + s].
  * bwd: dtable fp32 [V,d] = scatter-add of dx rows (deterministic order), row pad_id zero.
+ *      id_ws: int32 [2*V] scratch (first-occurrence / count tables, built with integer atomics).
  * --------------------------------------------------------------------------------------------- */
 int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids, int64_t id_batch_stride,
                   const void* table, const float* pos, void* x, const uint32_t* seed, uint32_t site,
                   float p_drop, void* stream);
 int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                  int64_t pad_id, const void* dx, float* dtable, const uint32_t* seed, uint32_t site,
-                  float p_drop, void* stream);
+                  int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, const uint32_t* seed,
+                  uint32_t site, float p_drop, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Symmetric cross-entropy loss + gradient w.r.t. logits, one workgroup per row, row held in LDS.
+ * Symmetric cross-entropy loss + gradient w.r.t. logits, one workgroup per row, row held in registers
+ * (one HBM read + one exp + one HBM write per logit).  Limits: ldl, ld_dl multiples of 8 (bf16) / 4 (fp32),
+ * >= V rounded up to that, and <= 65536 (bf16) / 32768 (fp32) columns.
  * replaces: SCELoss.forward (loss.py:78-92) / nn.CrossEntropyLoss(ignore_index) when alpha == 1
  * (CapDecoder.py:28-32,56-59) and their autograd backward.
  *   logits [N, ldl] (V valid columns); labels int64: row n = (b = n / S, s = n % S) ->

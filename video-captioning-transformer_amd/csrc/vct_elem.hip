@@ -87,68 +87,95 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int N, int S, int d, con
   }
 }
 
-// Deterministic scatter-add: the block of token position n owns table row ids[n] iff n is the FIRST
-// position holding that id; it then sums dx rows of every later occurrence in increasing position
-// order.  No float atomics, bitwise reproducible.  dtable must be zero-filled beforehand.
+// Deterministic scatter-add without float atomics.  Pass 1 (one thread per token position): integer
+// atomics build first_pos[id] = smallest position holding that id and cnt[id] = occurrences (both
+// order-independent).  Pass 2 (one workgroup per position): only the FIRST occurrence owns the
+// table row; a token seen once (the common case) is a straight row copy, a repeated token sums its
+// occurrences in increasing position order.  Bitwise reproducible; dtable is zero-filled first.
+__global__ void embed_index_kernel(int N, int S, const int64_t* __restrict__ ids, int64_t id_bstride, int64_t pad_id,
+                                   int32_t* __restrict__ first_pos, int32_t* __restrict__ cnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
+  if (id == pad_id) return;
+  atomicMin(&first_pos[id], n);
+  atomicAdd(&cnt[id], 1);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, const int64_t* __restrict__ ids,
                                                         int64_t id_bstride, int64_t pad_id, const T* __restrict__ dx,
-                                                        float* __restrict__ dtable, const uint32_t* seed, uint32_t site,
+                                                        float* __restrict__ dtable, const int32_t* __restrict__ first_pos,
+                                                        const int32_t* __restrict__ cnt, const uint32_t* seed, uint32_t site,
                                                         float p_drop) {
-  __shared__ int s_dup;
+  constexpr int VEC = EV<T>::VEC;
+  using P = PackT<T, VEC>;
   __shared__ int s_cnt;
+  __shared__ int s_wcnt[4];
   __shared__ int s_list[1024];
+  __shared__ float s_part[256 * VEC];                  // [slot][d] partial sums
   const int n = blockIdx.x;
-  const int b0 = n / S, s0 = n % S;
-  const int64_t id = ids[(size_t)b0 * id_bstride + s0];
-  if (id == pad_id) return;
-  if (threadIdx.x == 0) { s_dup = 0; s_cnt = 0; }
-  __syncthreads();
-  int dup = 0;
-  for (int j = threadIdx.x; j < n; j += blockDim.x) dup |= (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
-  if (dup) s_dup = 1;  // benign race: all writers store 1
-  __syncthreads();
-  if (s_dup) return;
+  const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
+  if (id == pad_id || first_pos[id] != n) return;       // not the owner of this table row
+  const int occurrences = cnt[id];
   const Dropout dr = make_dropout(seed, site, p_drop);
-  // later occurrences, processed in chunks of 1024 positions so the order stays increasing
-  float acc[8];
-  const int nd = d;  // thread t owns columns t, t+256, ...  (d <= 2048)
+  // thread = (occurrence slot, 16-byte column chunk): a frequent token ([CLS] sits in every caption)
+  // is summed by `slots` threads per column in parallel, each over a fixed subsequence of the
+  // ordered occurrence list; the slot partials are then added in slot order -> deterministic
+  const int chunks = d / VEC, slots = 256 / chunks;
+  const int chunk = threadIdx.x % chunks, slot = threadIdx.x / chunks;
+  const bool active = slot < slots;
+  float acc[VEC];
 #pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = 0.0f;
-  for (int base = n; base < N; base += 1024) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    // ordered compaction of matches in [base, base+1024): ballot per wave, prefix over waves
-    for (int sub = 0; sub < 1024; sub += 256) {
-      const int j = base + sub + threadIdx.x;
-      const bool match = (j < N) && (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
-      const unsigned long long bal = __ballot(match);
-      __shared__ int s_wcnt[4];
-      const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-      if (l == 0) s_wcnt[w] = __popcll(bal);
-      __syncthreads();
-      int off = s_cnt;
-      for (int ww = 0; ww < w; ww++) off += s_wcnt[ww];
-      if (match) s_list[off + __popcll(bal & ((1ull << l) - 1ull))] = j;
-      __syncthreads();
-      if (threadIdx.x == 0) s_cnt += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      __syncthreads();
-    }
-    const int cnt = s_cnt;
-    for (int q = 0; q < cnt; q++) {
-      const int j = s_list[q];
+  for (int j = 0; j < VEC; j++) acc[j] = 0.0f;
+  auto add_row = [&](int pos) {
+    const P v = *reinterpret_cast<const P*>(dx + (size_t)pos * d + chunk * VEC);
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int c = threadIdx.x + k * 256;
-        if (c < nd) acc[k] += to_f<T>(dx[(size_t)j * d + c]) * drop_mult(dr, (uint32_t)j * (uint32_t)d + (uint32_t)c);
+    for (int j = 0; j < VEC; j++)
+      acc[j] += to_f<T>(v.v[j]) * drop_mult(dr, (uint32_t)pos * (uint32_t)d + (uint32_t)(chunk * VEC + j));
+  };
+  if (occurrences == 1) {
+    if (active && slot == 0) add_row(n);
+  } else {
+    int seen = 0;                                       // occurrences consumed so far (global order index)
+    for (int base = n; base < N && seen < occurrences; base += 1024) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_cnt = 0;
+      __syncthreads();
+      for (int sub = 0; sub < 1024; sub += 256) {       // ordered compaction: ballot per wave, prefix over waves
+        const int j = base + sub + threadIdx.x;
+        const bool match = (j < N) && (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
+        const unsigned long long bal = __ballot(match);
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 0) s_wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int off = s_cnt;
+        for (int ww = 0; ww < w; ww++) off += s_wcnt[ww];
+        if (match) s_list[off + __popcll(bal & ((1ull << l) - 1ull))] = j;
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
       }
+      const int found = s_cnt;
+      if (active) {
+        // slot s takes list entries whose GLOBAL order index is congruent to s (mod slots)
+        int q = ((slot - seen) % slots + slots) % slots;
+        for (; q + slots < found; q += 2 * slots) { add_row(s_list[q]); add_row(s_list[q + slots]); }
+        if (q < found) add_row(s_list[q]);
+      }
+      seen += found;
     }
   }
+  __syncthreads();
+  if (active) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int c = threadIdx.x + k * 256;
-    if (c < nd) dtable[(size_t)id * d + c] = acc[k];
+    for (int j = 0; j < VEC; j++) s_part[slot * d + chunk * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float s = 0.0f;
+    for (int sl = 0; sl < slots; sl++) s += s_part[sl * d + c];
+    dtable[(size_t)id * d + c] = s;
   }
 }
 
@@ -166,15 +193,15 @@ __global__ void count_valid_kernel(int N, int S, const int64_t* __restrict__ lab
 
 constexpr float SCE_C = 9.210340371976184f;  // -log(1e-4): loss.py:86-88 off-target log(clamp(onehot))
 
-// The row is staged in LDS in its STORAGE type (bf16 rows take 61 KB -> two workgroups per CU, so one
-// row's HBM latency hides under the other's passes); exp(x - max) is recomputed in each pass.
-template <typename T>
-__global__ __launch_bounds__(1024) void sce_loss_kernel(int N, int S, int V, const T* __restrict__ logits, int64_t ldl,
+// One NT-thread workgroup per row; the row lives in REGISTERS (IT 16-byte vectors per thread, loaded
+// once from HBM), so every logit costs one HBM read, one exp and one HBM write (the gradient), and
+// LDS only carries the block reductions.  NT*IT vectors must cover the row: 256 x 16 (default: few waves per
+// barrier, 16 loads in flight per thread, 3 rows per CU) or 1024 x 8 for very wide vocabularies.
+template <typename T, int IT, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, int V, const T* __restrict__ logits, int64_t ldl,
                                                         const int64_t* __restrict__ labels, int64_t lbstride,
                                                         int64_t pad_id, float alpha, T* __restrict__ dlogits, int64_t ld_dl,
                                                         float* __restrict__ row_ws) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char row_raw[];
-  T* row = reinterpret_cast<T*>(row_raw);
   __shared__ float red[16];
   constexpr int VEC = EV<T>::VEC;
   using P = PackT<T, VEC>;
@@ -183,84 +210,83 @@ __global__ __launch_bounds__(1024) void sce_loss_kernel(int N, int S, int V, con
   const int64_t y = labels[(size_t)(n / S) * lbstride + (n % S)];
   const bool valid = (y != pad_id);
   const float nvalid = row_ws[2 * N];
-  const int nv = (V + VEC - 1) / VEC;   // LDS row is padded to a whole vector
-  const bool vec_in = (ldl % VEC == 0) && (((uintptr_t)logits & 15) == 0);
-  // pass 1: stage the row (16-byte loads), running max
+  const float xy = to_f<T>(x[y]);
+  const int nv = (V + VEC - 1) / VEC;                 // vectors holding valid columns (ldl covers the rounded-up row)
+  // all IT loads are issued back to back, unconditionally (index clamped, out-of-row vectors masked after)
+  P pk[IT];
+#pragma unroll
+  for (int it = 0; it < IT; it++) pk[it] = *reinterpret_cast<const P*>(x + (size_t)min(it * NT + tid, nv - 1) * VEC);
+  float e[IT][VEC];
   float mx = -INFINITY;
-  if (vec_in) {
-    for (int vi = tid; vi < nv; vi += 1024) {
-      const P pk = *reinterpret_cast<const P*>(x + vi * VEC);
-      *reinterpret_cast<P*>(row + vi * VEC) = pk;
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int vi = it * NT + tid;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) e[it][j] = to_f<T>(pk[it].v[j]);
+    if (vi >= nv - 1) {                                // only the last vector of the row (and beyond) needs masking
 #pragma unroll
       for (int j = 0; j < VEC; j++)
-        if (vi * VEC + j < V) mx = fmaxf(mx, to_f<T>(pk.v[j]));
+        if (vi >= nv || vi * VEC + j >= V) e[it][j] = -INFINITY;
     }
-  } else {
-    for (int j = tid; j < V; j += 1024) { const T v = x[j]; row[j] = v; mx = fmaxf(mx, to_f<T>(v)); }
-  }
-  mx = block_max<16>(mx, red);   // also makes the staged row visible
-  const float xy = to_f<T>(row[y]);
-  // pass 2: sum of exp(x - max)
-  float se = 0.0f;
-  for (int vi = tid; vi < nv; vi += 1024) {
-    const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
 #pragma unroll
-    for (int j = 0; j < VEC; j++)
-      if (vi * VEC + j < V) se += __expf(to_f<T>(pk.v[j]) - mx);
+    for (int j = 0; j < VEC; j++) mx = fmaxf(mx, e[it][j]);
   }
-  se = block_sum<16>(se, red);
+  mx = block_max<NT / 64>(mx, red);
+  float se = 0.0f;
+#pragma unroll
+  for (int it = 0; it < IT; it++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { e[it][j] = __expf(e[it][j] - mx); se += e[it][j]; }   // padding: exp(-inf) = 0
+  se = block_sum<NT / 64>(se, red);
   const float inv = 1.0f / se;
   const float beta = 1.0f - alpha;
-  // pass 3: Q = sum_{j != y, p_j >= 1e-7} p_j ; cnt = #{j != y : p_j < 1e-7}
+  const float py = __expf(xy - mx) * inv;
+  // over ALL columns: Qa = sum_{p_j >= 1e-7} p_j, ca = #{p_j < 1e-7} (padding has p = 0 and is counted: fixed below);
+  // the label column is then taken out analytically -- no per-element (j != y) tests
   float q = 0.0f, cnt = 0.0f;
   if (alpha != 1.0f) {
-    for (int vi = tid; vi < nv; vi += 1024) {
-      const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
+#pragma unroll
+    for (int it = 0; it < IT; it++)
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
-        const int c = vi * VEC + j;
-        if (c < V && c != y) {
-          const float pj = __expf(to_f<T>(pk.v[j]) - mx) * inv;
-          if (pj >= 1e-7f) q += pj; else cnt += 1.0f;
-        }
+        const float pj = e[it][j] * inv;
+        const bool big = pj >= 1e-7f;
+        q += big ? pj : 0.0f;
+        cnt += big ? 0.0f : 1.0f;
       }
-    }
-    q = block_sum<16>(q, red);
-    cnt = block_sum<16>(cnt, red);
+    q = block_sum<NT / 64>(q, red);
+    cnt = block_sum<NT / 64>(cnt, red);
+    cnt -= (float)(IT * NT * VEC - V);                 // masked / padding slots were counted as "small"
+    if (py >= 1e-7f) q -= py; else cnt -= 1.0f;        // remove the label column
   }
   if (tid == 0) {
     row_ws[n] = valid ? (mx + __logf(se)) - xy : 0.0f;
     row_ws[N + n] = SCE_C * (q + 1e-7f * cnt);
   }
   if (dlogits == nullptr) return;
-  // pass 4: gradient  a*(p - 1[j==y]) + (beta/N) * p * (G_j - c*Q),  G_j = c*[j != y][p_j >= 1e-7]
+  // gradient for j != y:  p_j * (a + bn*(G_j - c*Q)),  G_j = c*[p_j >= 1e-7]; padding has p = 0 -> 0
   const float a = valid ? alpha / nvalid : 0.0f;
   const float bn = (alpha != 1.0f) ? beta / (float)N : 0.0f;
-  const float cq = SCE_C * q;
+  const float k_small = a - bn * SCE_C * q;            // multiplier when p_j <  1e-7
+  const float k_big = k_small + bn * SCE_C;            // multiplier when p_j >= 1e-7
   T* dx = dlogits + (size_t)n * ld_dl;
-  auto grad_of = [&](int j, float xv) -> float {
-    if (j >= V) return 0.0f;
-    const float pj = __expf(xv - mx) * inv;
-    const float G = (j != y && pj >= 1e-7f) ? SCE_C : 0.0f;
-    return a * (pj - (j == y ? 1.0f : 0.0f)) + bn * pj * (G - cq);
-  };
-  if ((ld_dl % VEC == 0) && (((uintptr_t)dlogits & 15) == 0)) {
-    const int nvo = (int)(ld_dl / VEC);
-    for (int vi = tid; vi < nvo; vi += 1024) {
+  const int nvo = (int)(ld_dl / VEC);
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int vi = it * NT + tid;
+    if (vi < nvo) {
       P o;
-      if (vi < nv) {
-        const P pk = *reinterpret_cast<const P*>(row + vi * VEC);
 #pragma unroll
-        for (int j = 0; j < VEC; j++) o.v[j] = from_f<T>(grad_of(vi * VEC + j, to_f<T>(pk.v[j])));
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; j++) o.v[j] = from_f<T>(0.0f);
+      for (int j = 0; j < VEC; j++) {
+        const float pj = e[it][j] * inv;
+        o.v[j] = from_f<T>(pj * (pj >= 1e-7f ? k_big : k_small));
       }
       *reinterpret_cast<P*>(dx + vi * VEC) = o;
     }
-  } else {
-    for (int j = tid; j < (int)ld_dl; j += 1024) dx[j] = from_f<T>(j < V ? grad_of(j, to_f<T>(row[j])) : 0.0f);
   }
+  // the label column: a*(p_y - 1) + bn*p_y*(0 - c*Q)   (written after the row's vector stores)
+  __syncthreads();
+  if (tid == 0) dx[y] = from_f<T>(a * (py - 1.0f) - bn * py * SCE_C * q);
 }
 
 __global__ void sce_finalize_kernel(int N, float alpha, const float* __restrict__ row_ws, float* __restrict__ loss) {
@@ -375,21 +401,29 @@ extern "C" int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids,
 }
 
 extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                             int64_t pad_id, const void* dx, float* dtable, const uint32_t* seed, uint32_t site,
-                             float p_drop, void* stream) {
-  if (!dt_ok(dtype) || !ids || !dx || !dtable) return VCT_E_ARG;
+                             int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, const uint32_t* seed,
+                             uint32_t site, float p_drop, void* stream) {
+  if (!dt_ok(dtype) || !ids || !dx || !dtable || !id_ws) return VCT_E_ARG;
   if (B <= 0 || S <= 0 || d <= 0 || V <= 0) return VCT_E_SHAPE;
-  if (d > 2048) return VCT_E_SHAPE;
+  if (d % vec_of(dtype) || d / vec_of(dtype) > 256) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(dtable, 0, (size_t)V * d * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
+  int32_t* first_pos = id_ws;
+  int32_t* cnt = id_ws + V;
+  e = hipMemsetAsync(first_pos, 0x7f, (size_t)V * sizeof(int32_t), st);   // 0x7f7f7f7f: larger than any position
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(cnt, 0, (size_t)V * sizeof(int32_t), st);
+  if (e != hipSuccess) return (int)e;
   const int N = B * S;
+  hipLaunchKernelGGL(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt);
+  VCT_CHECK_LAUNCH();
   if (dtype == VCT_BF16)
     hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const bf16_t*)dx, dtable, seed, site, p_drop);
+                       (const bf16_t*)dx, dtable, first_pos, cnt, seed, site, p_drop);
   else
     hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const float*)dx, dtable, seed, site, p_drop);
+                       (const float*)dx, dtable, first_pos, cnt, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -399,34 +433,21 @@ extern "C" int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, 
                             int64_t ld_dl, float* row_ws, void* stream) {
   if (!dt_ok(dtype) || !logits || !labels || !loss_out || !row_ws) return VCT_E_ARG;
   if (N <= 0 || S <= 0 || V <= 0 || N % S) return VCT_E_SHAPE;
-  const size_t esz = dtype == VCT_BF16 ? 2 : 4;
-  if (((size_t)V + 8) * esz > 160 * 1024 - 256) return VCT_E_SHAPE;  // row must fit in one CU's LDS
-  if (ldl < V || (dlogits && ld_dl < V)) return VCT_E_SHAPE;
+  const int vec = vec_of(dtype);
+  const int64_t vround = ((int64_t)V + vec - 1) / vec * vec;
+  if (ldl < vround || ldl % vec || ((uintptr_t)logits & 15)) return VCT_E_ALIGN;       // rows are read as 16-byte vectors
+  if (dlogits && (ld_dl < vround || ld_dl % vec || ((uintptr_t)dlogits & 15))) return VCT_E_ALIGN;
+  if (ld_dl > (int64_t)8 * 1024 * vec || vround > (int64_t)8 * 1024 * vec) return VCT_E_SHAPE;   // row must fit the register tile
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, st, N, S, labels, label_batch_stride, pad_id, row_ws + 2 * (size_t)N);
   VCT_CHECK_LAUNCH();
-  const size_t shmem = (((size_t)V + 7) / 8 * 8 + 8) * esz;
-  if (dtype == VCT_BF16) {
-    auto kfn = sce_loss_kernel<bf16_t>;
-    static int attr_bf16 = 0;
-    if ((int)shmem > attr_bf16) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return (int)e;
-      attr_bf16 = (int)shmem;
-    }
-    hipLaunchKernelGGL(kfn, dim3(N), dim3(1024), shmem, st, N, S, V, (const bf16_t*)logits, ldl, labels, label_batch_stride,
-                       pad_id, alpha, (bf16_t*)dlogits, ld_dl, row_ws);
-  } else {
-    auto kfn = sce_loss_kernel<float>;
-    static int attr_f32 = 0;
-    if ((int)shmem > attr_f32) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      if (e != hipSuccess) return (int)e;
-      attr_f32 = (int)shmem;
-    }
-    hipLaunchKernelGGL(kfn, dim3(N), dim3(1024), shmem, st, N, S, V, (const float*)logits, ldl, labels, label_batch_stride,
-                       pad_id, alpha, (float*)dlogits, ld_dl, row_ws);
-  }
+  const int64_t width = dlogits ? (ld_dl > vround ? ld_dl : vround) : vround;
+  const bool small = width <= (int64_t)4 * 1024 * vec;
+#define VCT_SCE(T_, IT_, NT_) hipLaunchKernelGGL((sce_loss_kernel<T_, IT_, NT_>), dim3(N), dim3(NT_), 0, st, N, S, V, (const T_*)logits, ldl, \
+                                                 labels, label_batch_stride, pad_id, alpha, (T_*)dlogits, ld_dl, row_ws)
+  if (dtype == VCT_BF16) { if (small) VCT_SCE(bf16_t, 4, 1024); else VCT_SCE(bf16_t, 8, 1024); }
+  else { if (small) VCT_SCE(float, 4, 1024); else VCT_SCE(float, 8, 1024); }
+#undef VCT_SCE
   VCT_CHECK_LAUNCH();
   hipLaunchKernelGGL(sce_finalize_kernel, dim3(1), dim3(1024), 0, st, N, alpha, row_ws, loss_out);
   VCT_CHECK_LAUNCH();

@@ -156,11 +156,20 @@ def embed_fwd(ids, S, table, pos, x, dropout: Drop = None):
     return x
 
 
-def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None):
+_embed_ws = {}
+
+
+def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None):
     B = ids.shape[0]
     s, site, p = _drop(dropout)
-    L.check(L.load().vct_embed_bwd(L.dtype_code(dx.dtype), B, S, dx.shape[1], dtable.shape[0], ids.data_ptr(),
-                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), s, site, p,
+    V = dtable.shape[0]
+    if id_ws is None:
+        key = (V, dx.device)
+        id_ws = _embed_ws.get(key)
+        if id_ws is None:
+            id_ws = _embed_ws[key] = torch.empty(2 * V, dtype=torch.int32, device=dx.device)
+    L.check(L.load().vct_embed_bwd(L.dtype_code(dx.dtype), B, S, dx.shape[1], V, ids.data_ptr(),
+                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), id_ws.data_ptr(), s, site, p,
                                    L.stream_ptr()), "vct_embed_bwd")
 
 
