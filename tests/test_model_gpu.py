@@ -333,3 +333,48 @@ def test_graph_captured_train_step_matches_eager():
     assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
     assert outs[0][0][-1] < outs[0][0][0]      # and it learns
+
+
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 3e-2, 8e-2)])
+def test_cfgD_deep_ragged_vs_oracle(dtype, tl, tg):
+    """BASELINE.json configs[3] shape family (d=1024, head_dim 128, 32 frames, 40 tokens) with fewer layers and
+    a small vocabulary so the CPU oracle finishes in seconds; ragged captions AND padded videos."""
+    mc = {"modal": ["CLIP4Clip"], "modal_shape": [512], "tokenizer": "ids", "text_enc_type": "CLIP", "embed_dim": 1024,
+          "dropout": 0.0, "loss_beta": 0.5, "matching": None, "activation": "gelu",
+          "video_encoder": {"layer": 2, "nhead": 8, "feedforward": 2048, "mme": {"temporal": "encoding", "do_norm": False, "aggregation": "avg"}},
+          "caption_decoder": {"layer": 2, "nhead": 8, "feedforward": 2048, "sce_loss_alpha": 0.5}, "pretrained_model": None}
+    V = 1531
+    cfg = O.cfg_from_model_config(mc, V)
+    p = O.init_params(cfg, seed=21)
+    f, mk, ids = O.synthetic_batch(5, 32, 512, 40, V, seed=3, ragged=True)
+    ref_loss, ref_grads, ref_logits = O.caption_loss_and_grads(p, cfg, f, mk, ids)
+    m = build_model(mc, V, DEV, dtype, p)
+    m.train()
+    feats, mask, idt = torch.from_numpy(f).to(DEV), torch.from_numpy(mk).to(DEV), torch.from_numpy(ids).to(DEV)
+    loss, logits = m._forward_loss(feats, mask, idt, True, want_logits=True)
+    assert rel(logits[:, :V].reshape(ref_logits.shape), ref_logits) < tl
+    assert abs(float(loss) - ref_loss) < (1e-5 if dtype == torch.float32 else 2e-3) * abs(ref_loss)
+    m._backward()
+    for k, g in ref_grads.items():
+        assert rel(m._ps.g[k], g) < tg, k
+    if dtype == torch.float32:
+        ys = m.greedy_decode_ids([feats[:2]], None, max_len=20)
+        assert np.array_equal(ys.cpu().numpy(), O.greedy_decode_ids(p, cfg, f[:2], None, max_len=20))
+
+
+def test_shipped_config_shape_trains_on_gpu():
+    """The shipped JSON's shape (d=768: head_dim 96, 1 enc + 3 dec layers, matching.v_proj present) through the API."""
+    from test_host_logic_cpu import SHIPPED_LIKE
+    mc = dict(SHIPPED_LIKE, dropout=0.0)
+    cfg = O.cfg_from_model_config(mc, 997)
+    p = O.init_params(cfg, seed=8)
+    m = build_model(mc, 997, DEV, torch.float32, p)
+    m.train()
+    f, mk, ids = O.synthetic_batch(3, 12, 512, 9, 997, seed=2, ragged=True)
+    ref_loss, ref_grads, _ = O.caption_loss_and_grads(p, cfg, f, mk, ids)
+    loss = m([torch.from_numpy(f).to(DEV)], [torch.from_numpy(mk).to(DEV)], torch.from_numpy(ids).to(DEV))
+    loss.backward()
+    assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+    for k, g in ref_grads.items():
+        assert rel(dict(m.named_parameters())[k].grad, g) < 1e-3, k
+    assert m.matching.v_proj.weight.grad is None and not m.matching.v_proj.weight.requires_grad

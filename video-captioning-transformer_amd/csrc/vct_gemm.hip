@@ -373,6 +373,7 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
       // (K >= 4096: the vocabulary / token dimension) amortises 128x128 tiles (+ split-K when legal)
       pick = 3;
       if (pl.nkt >= 64 && tiles(128, 128) >= 128) pick = 0;
+      else if (tiles(64, 64) >= 16384 && d->N >= 4096) pick = 2;   // vocabulary projection: 64x128 (545 vs 524 TF)
     }
     pl.bm = cand[pick][0]; pl.bn = cand[pick][1];
   } else {
