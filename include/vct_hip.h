@@ -125,6 +125,10 @@ int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const
                    float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
                    float p_drop, void* stream);
 int vct_ln_ws_rows(int M);
+/* dgamma == dbeta == NULL in vct_add_ln_bwd defers the column reduction of param_ws; this call then finalizes
+ * n_entries LayerNorms in ONE launch.  table_dev: DEVICE int64 [n_entries][4] = {param_ws ptr, dgamma ptr,
+ * dbeta ptr, vct_ln_ws_rows(M)} (every param_ws must stay untouched until then). */
+int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder front end after the `unify` GEMM: z[b,0] = mean_t u[b,t] (all T rows, pads included),

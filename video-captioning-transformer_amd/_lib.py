@@ -42,6 +42,7 @@ _SIGS = {
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_ln_ws_rows": (C.c_int, [C.c_int]),
+    "vct_ln_param_finalize_batched": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "vct_enc_frontend_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "vct_enc_frontend_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "vct_embed_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, u32, f32, vp]),

@@ -199,6 +199,32 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(int nws, int d, 
   }
 }
 
+// batched form: one launch finalizes the dgamma/dbeta of several LayerNorms (table of 4 x int64 per
+// entry: partials pointer, dgamma pointer, dbeta pointer, number of partial rows)
+__global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const int64_t* __restrict__ table, int d) {
+  __shared__ float red[16][17];
+  const int64_t* ent = table + (size_t)blockIdx.y * 4;
+  const float* ws = reinterpret_cast<const float*>(ent[0]);
+  float* dgamma = reinterpret_cast<float*>(ent[1]);
+  float* dbeta = reinterpret_cast<float*>(ent[2]);
+  const int nws = (int)ent[3];
+  const int cx = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  float s = 0.0f;
+  if (c < 2 * d) {
+    const int which = c / d, col = c % d;
+    for (int r = rg; r < nws; r += 16) s += ws[((size_t)r * 2 + which) * d + col];
+  }
+  red[rg][cx] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * d) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][cx];
+    (c < d ? dgamma : dbeta)[c % d] = t;
+  }
+}
+
 }  // namespace vct
 using namespace vct;
 
@@ -240,7 +266,8 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
                               float p_drop, void* stream) {
   int rc = ln_check(dtype, M, d);
   if (rc) return rc;
-  if (!dy || !x || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta || !param_ws) return VCT_E_ARG;
+  if (!dy || !x || !gamma || !mean || !rstd || !ds || !param_ws) return VCT_E_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return VCT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nws = vct_ln_ws_rows(M);
   const dim3 grid(nws);
@@ -251,7 +278,18 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
     hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
                        (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
+  if (dgamma != nullptr && dbeta != nullptr) {   // NULL: the caller finalizes later with vct_ln_param_finalize_batched
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
+    VCT_CHECK_LAUNCH();
+  }
+  return VCT_OK;
+}
+
+extern "C" int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream) {
+  if (!table_dev) return VCT_E_ARG;
+  if (n_entries <= 0 || d <= 0) return VCT_E_SHAPE;
+  hipLaunchKernelGGL(ln_param_finalize_batched_kernel, dim3((2 * d + 15) / 16, n_entries), dim3(256), 0, (hipStream_t)stream,
+                     table_dev, d);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

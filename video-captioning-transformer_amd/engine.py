@@ -115,6 +115,7 @@ class _StackBase:
         self.bufs: Dict[tuple, _Buf] = {}
         self.p_drop = 0.0
         self._ws = None
+        self._ln_pending = []
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
     def W(self, k): return self.ps.c[self.pre + k]
@@ -198,15 +199,30 @@ class _StackBase:
         return y
 
     def _ln_bwd(self, b, tag, np_, dy, x, res, site):
-        """Returns (ds, dxo): gradient of the pre-norm sum and its dropout-masked copy."""
+        """Returns (ds, dxo): gradient of the pre-norm sum and its dropout-masked copy.  The column
+        reduction of the dgamma/dbeta partials is deferred: flush_ln_grads() does all of them in one launch."""
         M, d = x.shape
         ds = b.get(tag + "ds", (M, d), self.dt)
         drop = self.drop(site) if site is not None else None
         dxo = b.get(tag + "dxo", (M, d), self.dt) if drop is not None else ds
+        ws = b.get(tag + "ln_ws", (2 * ops.ln_ws_rows(M) * d,), torch.float32)     # one per LayerNorm (kept until the flush)
         ops.add_ln_bwd(dy, x, res, self.F(np_ + "weight"), b.t[tag + "mean"], b.t[tag + "rstd"], ds, dxo,
-                       self.G(np_ + "weight"), self.G(np_ + "bias"),
-                       b.get("ln_ws", (2 * ops.ln_ws_rows(M) * d,), torch.float32), dropout=drop)
+                       None, None, ws, dropout=drop)
+        self._ln_pending.append((ws.data_ptr(), self.G(np_ + "weight").data_ptr(), self.G(np_ + "bias").data_ptr(),
+                                 ops.ln_ws_rows(M)))
         return ds, dxo
+
+    def flush_ln_grads(self, b):
+        """One launch: dgamma/dbeta of every LayerNorm whose backward ran since the last flush."""
+        if not self._ln_pending:
+            return
+        key = tuple(self._ln_pending)
+        tab = b.t.get(("ln_table", key))
+        if tab is None:       # pointers are static per shape configuration: the table is uploaded once
+            tab = torch.tensor(self._ln_pending, dtype=torch.int64).to(self.dev)
+            b.t[("ln_table", key)] = tab
+        ops.ln_param_finalize_batched(tab, len(self._ln_pending), self.cfg["d"])
+        self._ln_pending = []
 
     def _ffn_fwd(self, b, tag, lp, x, site):
         M, d = x.shape
@@ -302,6 +318,7 @@ class EncoderEngine(_StackBase):
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
         ops.gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"),
                  workspace=self.gemm_ws())
+        self.flush_ln_grads(b)
 
 
 class DecoderEngine(_StackBase):
@@ -392,6 +409,7 @@ class DecoderEngine(_StackBase):
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+        self.flush_ln_grads(b)
         if bucket_ready is not None:
             bucket_ready(1)
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))

@@ -130,8 +130,13 @@ def add_ln_bwd(dy, x, res, gamma, mean, rstd, ds, dxo, dgamma, dbeta, param_ws, 
     s, site, p = _drop(dropout)
     L.check(L.load().vct_add_ln_bwd(L.dtype_code(x.dtype), M, dm, dy.data_ptr(), x.data_ptr(), L.ptr(res),
                                     gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ds.data_ptr(), L.ptr(dxo),
-                                    dgamma.data_ptr(), dbeta.data_ptr(), param_ws.data_ptr(), s, site, p,
+                                    L.ptr(dgamma), L.ptr(dbeta), param_ws.data_ptr(), s, site, p,
                                     L.stream_ptr()), "vct_add_ln_bwd")
+
+
+def ln_param_finalize_batched(table, n_entries, d):
+    """table: int64 device tensor [n_entries, 4] = (param_ws ptr, dgamma ptr, dbeta ptr, ws rows)."""
+    L.check(L.load().vct_ln_param_finalize_batched(table.data_ptr(), n_entries, d, L.stream_ptr()), "vct_ln_param_finalize_batched")
 
 
 def enc_frontend_fwd(u, pe_rows, z, B, T):
