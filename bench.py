@@ -165,6 +165,13 @@ def main():
         fl = algorithmic_flops(args.batch)
         kern = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in taps.items() if v}   # ms per launch
         dom = max(kern, key=kern.get)
+        traffic = None        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")))
+            if args.batch == 256 and args.dtype == "bf16":
+                traffic = tj[dom]["hbm_bytes"]
+        except Exception:
+            traffic = None
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = fl["gen"] / (kern[dom] * 1e-3) / 1e12
         ms = elapsed / args.steps * 1e3
@@ -180,11 +187,12 @@ def main():
                        "hipgraph_step": bool(trainer.use_graph)},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),
-            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd (vct_gemm NT, 128x128 tiles)",
+            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd (vct_gemm NT bf16, 64x128 tiles)",
                                                      "gen_dx": "generator dX GEMM (vct_gemm NN)",
                                                      "gen_dw": "generator dW GEMM (vct_gemm TN)"}[dom],
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None, "flops_per_launch": fl["gen"], "avg_ms_per_launch": round(kern[dom], 4),
+                         "traffic": traffic, "traffic_source": "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_roofline_traffic.json",
+                         "flops_per_launch": fl["gen"], "avg_ms_per_launch": round(kern[dom], 4),
                          "all_ms": {k: round(v, 4) for k, v in kern.items()}},
             "loss": final_loss,
         }
