@@ -130,6 +130,31 @@ class _StackBase:
             self._ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.dev)
         return self._ws
 
+    # ---- weight-gradient GEMMs on a side HIP stream ---------------------------------------------
+    # dW = dY^T X only depends on dY (just produced) and X (saved), and nothing downstream in backward
+    # reads it: it runs on a second stream beside the dX chain so two half-empty grids share the CUs.
+    overlap_dw = True
+    _side = None
+    _side_ws = None
+
+    def dw_gemm(self, *args, **kw):
+        if not (self.overlap_dw and self.dev.type == "cuda"):
+            return ops.gemm(*args, workspace=self.gemm_ws(), **kw)
+        cls = _StackBase
+        if cls._side is None:
+            cls._side = torch.cuda.Stream(device=self.dev)
+            cls._side_ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.dev)
+        main = torch.cuda.current_stream()
+        cls._side.wait_stream(main)
+        with torch.cuda.stream(cls._side):
+            ops.gemm(*args, workspace=cls._side_ws, **kw)
+
+    def join_side(self):
+        """Main stream waits for every weight-gradient GEMM issued so far (before a gradient bucket is
+        handed to the exchange / the optimizer)."""
+        if _StackBase._side is not None and self.overlap_dw:
+            torch.cuda.current_stream().wait_stream(_StackBase._side)
+
     def buf(self, key) -> _Buf:
         b = self.bufs.get(key)
         if b is None:
@@ -168,7 +193,7 @@ class _StackBase:
         o = b.t[tag + "o"]
         d_o = b.get(tag + "d_o", (Mq, d), self.dt)
         ops.gemm(da, self.W(lp + "out_proj.weight"), d_o, ta=False, tb=False)
-        ops.gemm(da, o, self.G(lp + "out_proj.weight"), ta=True, tb=False, bias_grad=self.G(lp + "out_proj.bias"), workspace=ws)
+        self.dw_gemm(da, o, self.G(lp + "out_proj.weight"), ta=True, tb=False, bias_grad=self.G(lp + "out_proj.bias"))
         dx = b.get(tag + "dx", (Mq, d), self.dt)
         if self_attn:
             qkv = b.t[tag + "qkv"]
@@ -176,7 +201,7 @@ class _StackBase:
             ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], d_o, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                          Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=self.drop(site))
             ops.gemm(dqkv, self.W(lp + "in_proj_weight"), dx, ta=False, tb=False, addend=ds_res)
-            ops.gemm(dqkv, x, self.G(lp + "in_proj_weight"), ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias"), workspace=ws)
+            self.dw_gemm(dqkv, x, self.G(lp + "in_proj_weight"), ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias"))
         else:
             q, kv = b.t[tag + "q"], b.t[tag + "kv"]
             dq = b.get(tag + "dq", (Mq, d), self.dt)
@@ -184,11 +209,11 @@ class _StackBase:
             ops.attn_bwd(q, kv[:, :d], kv[:, d:], d_o, dq, dkv[:, :d], dkv[:, d:], Bn, H, Lq, Lk, causal=causal,
                          key_pad=key_pad, dropout=self.drop(site))
             ops.gemm(dq, self.W(lp + "in_proj_weight")[:d], dx, ta=False, tb=False, addend=ds_res)
-            ops.gemm(dq, x, self.G(lp + "in_proj_weight")[:d], ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias")[:d], workspace=ws)
+            self.dw_gemm(dq, x, self.G(lp + "in_proj_weight")[:d], ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias")[:d])
             ops.gemm(dkv, self.W(lp + "in_proj_weight")[d:], dkv_out, ta=False, tb=False,
                      addend=dkv_out if dkv_accumulate else None)
-            ops.gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:], ta=True, tb=False,
-                     bias_grad=self.G(lp + "in_proj_bias")[d:], workspace=ws)
+            self.dw_gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:], ta=True, tb=False,
+                         bias_grad=self.G(lp + "in_proj_bias")[d:])
         return dx
 
     def _ln_fwd(self, b, tag, np_, x, res, site):
@@ -243,10 +268,10 @@ class _StackBase:
         dhpre = b.get(tag + "dhpre", (M, ff), self.dt)
         ops.gemm(df, self.W(lp + "linear2.weight"), dhpre, ta=False, tb=False, act=self.cfg["activation"],
                  dact_src=b.t[tag + "hpre"], dropout=self.drop(site))
-        ops.gemm(df, b.t[tag + "h"], self.G(lp + "linear2.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear2.bias"), workspace=ws)
+        self.dw_gemm(df, b.t[tag + "h"], self.G(lp + "linear2.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear2.bias"))
         dx = b.get(tag + "dxf", (M, d), self.dt)
         ops.gemm(dhpre, self.W(lp + "linear1.weight"), dx, ta=False, tb=False, addend=ds_res)
-        ops.gemm(dhpre, x, self.G(lp + "linear1.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear1.bias"), workspace=ws)
+        self.dw_gemm(dhpre, x, self.G(lp + "linear1.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear1.bias"))
         return dx
 
 
@@ -316,9 +341,9 @@ class EncoderEngine(_StackBase):
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
-        ops.gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"),
-                 workspace=self.gemm_ws())
+        self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"))
         self.flush_ln_grads(b)
+        self.join_side()
 
 
 class DecoderEngine(_StackBase):
@@ -393,9 +418,10 @@ class DecoderEngine(_StackBase):
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
         ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
-        ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
-                 workspace=self.gemm_ws(), tag="gen_dw")
+        self.dw_gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
+                     tag="gen_dw")
         if bucket_ready is not None:
+            self.join_side()
             bucket_ready(0)
         dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
         dmem = b.get("dmem", (Bn * Te, d), self.dt)
@@ -410,6 +436,7 @@ class DecoderEngine(_StackBase):
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
         self.flush_ln_grads(b)
+        self.join_side()
         if bucket_ready is not None:
             bucket_ready(1)
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
