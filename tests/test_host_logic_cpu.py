@@ -71,7 +71,13 @@ def test_flat_storage_views_order_and_buckets():
     b = m.grad_buckets()
     assert b[0][0] == 0 and b[-1][1] == ps.total
     assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
-    assert b[2] == (ps.offsets["cap_decoder.tgt_to_emb.weight"], ps.offsets["video_encoder.transformer_encoder.norm.weight"])
+    assert len(b) == 1 + 2 + 1 + 2     # generator | 2 decoder layers | embedding | 2 encoder layers
+    assert b[m.bucket_index("embedding")] == (ps.offsets["cap_decoder.tgt_to_emb.weight"], ps.offsets["video_encoder.transformer_encoder.norm.weight"])
+    assert b[m.bucket_index("generator")] == (0, ps.offsets["cap_decoder.decoder.norm.weight"])
+    a1, e1 = b[m.bucket_index("dec_layer", 1)]
+    assert a1 == ps.offsets["cap_decoder.decoder.norm.weight"] and e1 == ps.offsets["cap_decoder.decoder.layers.0.norm3.weight"]
+    a0, e0 = b[m.bucket_index("enc_layer", 0)]
+    assert a0 == ps.offsets["video_encoder.transformer_encoder.layers.0.norm2.weight"] and e0 == ps.total
     # state_dict round trip keeps the aliasing (load_state_dict copies in place)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     sd["cap_decoder.generator.bias"].fill_(0.5)

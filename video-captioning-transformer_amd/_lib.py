@@ -67,6 +67,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    _ensure_current()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is the product path and has no CPU/eager fallback. "
@@ -90,6 +91,25 @@ def load():
         pass
     _lib = lib
     return lib
+
+
+def _ensure_current():
+    """The in-tree libvct_hip.so must match csrc/: if the build stamp is stale (sources edited after the last
+    build) and hipcc is available, rebuild; never fall back to anything else."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_vct_build", os.path.join(_PKG, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        stamp = os.path.join(_PKG, "build", "stamp")
+        fresh = os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == mod._digest()
+        if not fresh and os.path.exists(mod._hipcc()):
+            import sys
+            print("[vct_amd] libvct_hip.so is missing or older than csrc/: rebuilding with hipcc ...", file=sys.stderr)
+            mod.build_library()
+    except Exception as e:   # a failed rebuild surfaces below as "library missing" or as a load error
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"could not build libvct_hip.so: {e}")
 
 
 def check(rc, what):

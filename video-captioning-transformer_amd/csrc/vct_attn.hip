@@ -48,12 +48,25 @@ __device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, long
   constexpr int VPR = C::HDK / C::VEC;
   struct alignas(16) V16 { uint32_t w[4]; };
   const int total = rows_alloc * VPR;
-  for (int idx = lane; idx < total; idx += 64) {
-    const int r = idx / VPR, c = (idx % VPR) * C::VEC;
-    V16 val;
-    val.w[0] = val.w[1] = val.w[2] = val.w[3] = 0u;
-    if (r < L && c < hd) val = *reinterpret_cast<const V16*>(g + (long)r * ld + c);
-    *reinterpret_cast<V16*>(lds + r * C::STR + c) = val;
+  // four 16-byte loads per lane are issued back to back, UNCONDITIONALLY (row / column clamped into the
+  // slice); padding is zeroed afterwards.  A predicated load here costs a branch + vmcnt(0) per vector.
+  for (int base = 0; base < total; base += 256) {
+    V16 val[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = min(base + u * 64 + lane, total - 1);
+      const int r = min(idx / VPR, L - 1), c = min((idx % VPR) * C::VEC, hd - C::VEC);
+      val[u] = *reinterpret_cast<const V16*>(g + (long)r * ld + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = base + u * 64 + lane;
+      if (idx < total) {
+        const int r = idx / VPR, c = (idx % VPR) * C::VEC;
+        if (r >= L || c >= hd) val[u].w[0] = val[u].w[1] = val[u].w[2] = val[u].w[3] = 0u;
+        *reinterpret_cast<V16*>(lds + r * C::STR + c) = val[u];
+      }
+    }
   }
 }
 

@@ -327,7 +327,7 @@ class EncoderEngine(_StackBase):
         b.t["x_last"] = x
         return self._ln_fwd(b, "nf.", "transformer_encoder.norm.", x, None, None)
 
-    def backward(self, dmem: torch.Tensor):
+    def backward(self, dmem: torch.Tensor, bucket_ready=None):
         b = self.cur
         B, T = self.shape
         Te, L = T + 1, self.cfg["layers"]
@@ -340,10 +340,16 @@ class EncoderEngine(_StackBase):
             dx1 = self._ffn_bwd(b, tag + "ff.", lp, df, x1, site + 3, ds2)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
+            if bucket_ready is not None and l > 0:
+                self.flush_ln_grads(b)
+                self.join_side()
+                bucket_ready("enc_layer", l)
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
         self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"))
         self.flush_ln_grads(b)
         self.join_side()
+        if bucket_ready is not None:
+            bucket_ready("enc_layer", 0)
 
 
 class DecoderEngine(_StackBase):
@@ -408,8 +414,8 @@ class DecoderEngine(_StackBase):
         return logits[:, :self.V]
 
     def backward(self, bucket_ready=None) -> torch.Tensor:
-        """d(loss) = 1.  Returns d(memory) [B*Te, d].  bucket_ready(i) is called when gradient bucket i of
-        MMT4Caption.grad_buckets() is complete (0 generator, 1 decoder stack, 2 token embedding)."""
+        """d(loss) = 1.  Returns d(memory) [B*Te, d].  bucket_ready(kind, layer) is called when a gradient bucket
+        of MMT4Caption.grad_buckets() is complete ('generator', 'dec_layer' l, 'embedding')."""
         b = self.cur
         Bn, Te, S = self.shape
         d, L, pad = self.cfg["d"], self.cfg["layers"], self.cfg["pad_id"]
@@ -422,7 +428,7 @@ class DecoderEngine(_StackBase):
                      tag="gen_dw")
         if bucket_ready is not None:
             self.join_side()
-            bucket_ready(0)
+            bucket_ready("generator")
         dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
         dmem = b.get("dmem", (Bn * Te, d), self.dt)
         for l in reversed(range(L)):
@@ -435,13 +441,15 @@ class DecoderEngine(_StackBase):
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+            if bucket_ready is not None:      # this layer's (and, for the top layer, the final norm's) gradients are complete
+                self.flush_ln_grads(b)
+                self.join_side()
+                bucket_ready("dec_layer", l)
         self.flush_ln_grads(b)
         self.join_side()
-        if bucket_ready is not None:
-            bucket_ready(1)
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
         if bucket_ready is not None:
-            bucket_ready(2)
+            bucket_ready("embedding")
         return dmem
 
 

@@ -107,12 +107,30 @@ class MMT4Caption(nn.Module):
 
     def grad_buckets(self):
         """Contiguous [start, end) element ranges of the flat gradient buffer in the order the backward
-        pass completes them: generator | decoder stack | token embedding | encoder (+ rest)."""
+        pass completes them: generator | decoder norm + top layer | ... | decoder layer 0 | token embedding |
+        encoder norm + top layer | ... | encoder layer 0 + unify (+ parameters outside the caption path)."""
         ps, o = self._ps, self._ps.offsets
-        emb = "cap_decoder.tgt_to_emb.weight"
-        dec0 = o["cap_decoder.decoder.norm.weight"]
-        enc0 = o["video_encoder.transformer_encoder.norm.weight"]
-        return [(0, dec0), (dec0, o[emb]), (o[emb], enc0), (enc0, ps.total)]
+        Ld, Le = self.cap_decoder.cfg["layers"], self.video_encoder.cfg["layers"]
+        cuts = [0, o["cap_decoder.decoder.norm.weight"]]
+        cuts += [o[f"cap_decoder.decoder.layers.{l}.norm3.weight"] for l in reversed(range(Ld - 1))]
+        cuts += [o["cap_decoder.tgt_to_emb.weight"], o["video_encoder.transformer_encoder.norm.weight"]]
+        cuts += [o[f"video_encoder.transformer_encoder.layers.{l}.norm2.weight"] for l in reversed(range(Le - 1))]
+        cuts.append(ps.total)
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+
+    def bucket_index(self, kind: str, layer: int = 0) -> int:
+        """Index into grad_buckets(): kind in {'generator', 'dec_layer', 'embedding', 'enc_layer'}; `layer` is the
+        layer whose backward just finished."""
+        Ld, Le = self.cap_decoder.cfg["layers"], self.video_encoder.cfg["layers"]
+        if kind == "generator":
+            return 0
+        if kind == "dec_layer":
+            return 1 + (Ld - 1 - layer)
+        if kind == "embedding":
+            return 1 + Ld
+        if kind == "enc_layer":
+            return 2 + Ld + (Le - 1 - layer)
+        raise ValueError(kind)
 
     # ---- engine-level forward/backward (no autograd) ------------------------------------------------
     def _forward_loss(self, feats, mask, ids, training, want_logits=False):
@@ -125,10 +143,12 @@ class MMT4Caption(nn.Module):
         return loss, logits
 
     def _backward(self, bucket_ready=None):
-        dmem = self.cap_decoder._engine().backward(bucket_ready)
-        self.video_encoder._engine().backward(dmem)
+        hook = None
         if bucket_ready is not None:
-            bucket_ready(3)
+            def hook(kind, layer=0):
+                bucket_ready(self.bucket_index(kind, layer))
+        dmem = self.cap_decoder._engine().backward(hook)
+        self.video_encoder._engine().backward(dmem, hook)
 
     def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor,
                            bucket_ready=None) -> torch.Tensor:
