@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce payload")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (N=1); the per-kernel roofline "
                     "timing then comes from an eager tail pass, so the default is eager launches")
+    ap.add_argument("--overlap-adam", action="store_true", help="A/B: Adam per gradient bucket on the side stream during backward (measured slower)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
@@ -134,6 +135,7 @@ def main():
     else:
         opt, _ = build_optimizer(TRAIN_CFG, model)
     trainer = CaptionTrainer(model, opt, ex, use_graph=args.graph)
+    trainer.overlap_adam = args.overlap_adam
     feats, mask, ids = synthetic(args.batch, rank, device)
 
     def sync():

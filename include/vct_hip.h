@@ -176,11 +176,14 @@ int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, int64_t ldl
  * arithmetic as torch's single-tensor Adam (no amsgrad).  step_dev: DEVICE int32 counter of steps
  * already taken (read for the bias corrections, then incremented by a 1-thread kernel).
  * shadow_bf16 may be NULL; elements [shadow_skip_begin, shadow_skip_end) get no shadow (the token
- * embedding is gathered from the fp32 master).  n must be a multiple of 4.
+ * embedding is gathered from the fp32 master; offsets relative to `param`).  n must be a multiple of 4.
+ * A step may be applied range by range (each range as soon as its gradients are final, on a side stream):
+ * pass bump_step = 0 for all ranges and finish with one call n = 0, bump_step = 1.
  * --------------------------------------------------------------------------------------------- */
 int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, void* stream);
+                  int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
+                  void* stream);
 
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */

@@ -52,17 +52,24 @@ using namespace vct;
 
 extern "C" int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, void* stream) {
+                             int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
+                             void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return VCT_E_ARG;
-  if (n <= 0 || (n & 3)) return VCT_E_SHAPE;
+  if (n < 0 || (n & 3)) return VCT_E_SHAPE;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VCT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {   // bump only
+    if (bump_step) { hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev); VCT_CHECK_LAUNCH(); }
+    return VCT_OK;
+  }
   const int64_t want = ((n >> 2) + 255) / 256;
   const int blocks = (int)(want > 8192 ? 8192 : want);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
                      beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end);
   VCT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
-  VCT_CHECK_LAUNCH();
+  if (bump_step) {
+    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    VCT_CHECK_LAUNCH();
+  }
   return VCT_OK;
 }

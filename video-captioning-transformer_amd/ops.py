@@ -205,8 +205,15 @@ def advance_seed(seed):
     L.check(L.load().vct_advance_seed(seed.data_ptr(), L.stream_ptr()), "vct_advance_seed")
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step_dev, skip=(0, 0)):
-    """Fused Adam/AdamW over flat fp32 buffers (+ bf16 shadow refresh).  step_dev: int32[1] device counter."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step_dev, skip=(0, 0), bump=True):
+    """Fused Adam/AdamW over flat fp32 buffers (+ bf16 shadow refresh).  step_dev: int32[1] device counter.
+    `param` may be a slice of the flat buffer (range-by-range stepping): pass the same slice of every buffer,
+    `skip` relative to the slice start, bump=False, and finish with adam_bump(step_dev)."""
     L.check(L.load().vct_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
                                    param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                   step_dev.data_ptr(), int(skip[0]), int(skip[1]), L.stream_ptr()), "vct_adam_step")
+                                   step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.stream_ptr()), "vct_adam_step")
+
+
+def adam_bump(step_dev):
+    L.check(L.load().vct_adam_step(step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), 0, 0,
+                                   0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, L.stream_ptr()), "vct_adam_step(bump)")
