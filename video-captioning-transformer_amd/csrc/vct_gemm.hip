@@ -12,6 +12,7 @@
 //  * fused epilogues: bias, GELU/ReLU (+ saving the pre-activation), counter-hash dropout,
 //    residual-gradient accumulate, activation-derivative multiply, bias gradient (row sums of op(A)
 //    via one extra MFMA against a ones fragment).
+#include <cstdlib>
 #include "vct_common.h"
 #include "vct_gemm_params.h"
 
@@ -346,7 +347,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, TO* __re
   }
 }
 
-struct Plan { int bm, bn, nbuf; int split; int tiles_m, tiles_n, nkt, kt_per; };
+struct Plan { int bm, bn, nbuf, waves8; int split; int tiles_m, tiles_n, nkt, kt_per; };
 
 static bool gemm_can_split(const vct_gemm_desc* d) {
   return d->bias == nullptr && d->act == VCT_ACT_NONE && d->preact == nullptr &&
@@ -357,23 +358,31 @@ static bool gemm_can_split(const vct_gemm_desc* d) {
 static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   Plan pl;
   pl.nbuf = 2;
+  pl.waves8 = 0;
   const bool bf = d->dtype == VCT_BF16;
   const int BK = bf ? 64 : 16;
   pl.nkt = (d->K + BK - 1) / BK;
   auto tiles = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
   if (bf) {
-    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
     int pick = 3;
     const int tsel = d->reserved % 10;
     pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
-    if (tsel >= 1 && tsel <= 4) pick = tsel - 1;
+    if (tsel == 5) { pick = 0; pl.waves8 = 1; pl.nbuf = 2; }        // 128x128, 8 waves
+    else if (tsel == 8) { pick = 1; pl.waves8 = 4; pl.nbuf = 2; }   // 128x64, 8 waves
+    else if (tsel >= 1 && tsel <= 4) pick = tsel - 1;
     else {
-      // measured on MI355X (tools/gemm_bench.py, cfg-B shapes): with K <= 2048 the kernel is bound by
-      // operand fetch + per-tile latency and 64x64 tiles (5 workgroups / CU) win; a long reduction
-      // (K >= 4096: the vocabulary / token dimension) amortises 128x128 tiles (+ split-K when legal)
+      // measured on MI355X (tools/gemm_bench.py, cfg-B shapes).  The kernel is bound by the rate at which a CU
+      // pulls operand tiles from L2 (~17 B/clk with 8 waves per CU issuing DMA, ~26 B/clk with 16-20), so:
+      //  * big GEMMs (vocabulary projection and its two gradients): 128x128 tile (64 FLOP/B) with EIGHT waves;
+      //  * wide-N, short-K layer GEMMs (QKV / FFN1 forward, FFN2 dX): 128x64 with eight waves;
+      //  * everything else (N = 512 outputs, weight gradients): 64x64 with four waves, 5 workgroups per CU.
       pick = 3;
-      if (pl.nkt >= 64 && tiles(128, 128) >= 128) pick = 0;
-      else if (tiles(64, 64) >= 16384 && d->N >= 4096) pick = 2;   // vocabulary projection: 64x128 (545 vs 524 TF)
+      static const bool legacy = getenv("VCT_GEMM_4WAVE_ONLY") != nullptr;   // A/B switch for the 8-wave variants
+      if ((pl.nkt >= 64 && tiles(128, 128) >= 128) || (tiles(64, 64) >= 16384 && d->N >= 4096)) {
+        pick = 0; pl.waves8 = legacy ? 0 : 1;
+        if (legacy && pl.nkt < 64) pick = 2;
+      } else if (!legacy && d->N >= 1024 && d->M >= 2048 && pl.nkt <= 16) { pick = 1; pl.waves8 = 4; }
     }
     pl.bm = cand[pick][0]; pl.bn = cand[pick][1];
   } else {
@@ -460,6 +469,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
   p.bias_grad = d->bias_grad;
   p.partial = nullptr; p.bias_partial = nullptr;
+  p.waves8 = pl.waves8;
   if (pl.split > 1) {
     p.partial = reinterpret_cast<float*>(d->workspace);
     p.bias_partial = p.partial + (size_t)pl.split * d->M * d->N;

@@ -36,13 +36,14 @@ template <int R> __device__ __forceinline__ int mc_off(int krow, int col) {  // 
 }
 
 // issue the DMA of one operand tile (full K tile, rows clamped)
-template <bool MC, int R>
+template <bool MC, int R, int NW>
 __device__ __forceinline__ void dma_tile(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext,
                                          int k0, int wave, int lane) {
-  constexpr int NI = R * 8 / 256;  // wave-instructions per wave (1 KiB each)
+  constexpr int NI = R * 8 / (64 * NW);  // wave-instructions per wave (1 KiB each)
+  static_assert(NI >= 1, "tile too small for this many waves");
 #pragma unroll
   for (int q = 0; q < NI; q++) {
-    const int ci = q * 4 + wave;  // 1-KiB chunk index
+    const int ci = q * NW + wave;  // 1-KiB chunk index
     const bf16_t* src;
     if constexpr (!MC) {
       const int row = ci * 8 + (lane >> 3);
@@ -68,13 +69,13 @@ __device__ __forceinline__ void dma_tile(unsigned char* lds, const bf16_t* __res
 
 // ragged last K tile: predicated 16-byte loads (zero fill) written into the same swizzled image
 struct alignas(16) V16b { uint32_t w[4]; };
-template <bool MC, int R>
+template <bool MC, int R, int NT>
 __device__ __forceinline__ void tail_tile(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext,
                                           int k0, int K, int tid) {
-  constexpr int NV = R * 8 / 256;
+  constexpr int NV = R * 8 / NT;
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    const int v = tid + i * 256;
+    const int v = tid + i * NT;
     V16b val; val.w[0] = val.w[1] = val.w[2] = val.w[3] = 0u;
     if constexpr (!MC) {
       const int row = v >> 3, c = v & 7;
@@ -107,21 +108,22 @@ __device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, in
   }
 }
 
-template <typename TO, int TA, int TB, int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
+template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const GemmP p) {
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
   constexpr bool KSPLIT = A_MC && B_MC;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int NW = WGM * WGN, NT = 64 * NW;         // waves / threads per workgroup
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int STG_STRIDE = WN + 4;
-  constexpr int STG_BYTES = 4 * 16 * STG_STRIDE * 4;
-  constexpr int NDMA = BM / 32 + BN / 32;               // DMA instructions per K tile per wave
+  constexpr int STG_BYTES = NW * 16 * STG_STRIDE * 4;
+  constexpr int NDMA = (BM + BN) * 8 / NT;               // DMA instructions per K tile per wave
   static_assert(NBUF * BUF_BYTES >= STG_BYTES, "staging must fit");
   __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[NBUF * BUF_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware tile map (bijective for any tile count)
   const int nwg = p.tiles_m * p.tiles_n;
@@ -192,11 +194,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
   auto stage = [&](int kt, int buf) {
     unsigned char* nb = lds_raw + buf * BUF_BYTES;
     if (kt < kt_full_end) {
-      dma_tile<A_MC, BM>(nb, A, p.lda, m0, p.M, kt * BK2, wave, lane);
-      dma_tile<B_MC, BN>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, wave, lane);
+      dma_tile<A_MC, BM, NW>(nb, A, p.lda, m0, p.M, kt * BK2, wave, lane);
+      dma_tile<B_MC, BN, NW>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, wave, lane);
     } else {
-      tail_tile<A_MC, BM>(nb, A, p.lda, m0, p.M, kt * BK2, p.K, tid);
-      tail_tile<B_MC, BN>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, p.K, tid);
+      tail_tile<A_MC, BM, NT>(nb, A, p.lda, m0, p.M, kt * BK2, p.K, tid);
+      tail_tile<B_MC, BN, NT>(nb + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, p.K, tid);
     }
   };
   // NBUF = 1: stage -> wait -> barrier -> compute -> barrier (smallest LDS, most workgroups per CU)
@@ -352,7 +354,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_v2_kernel(const GemmP p) {
 template <typename TO, int TA, int TB, int NBUF>
 static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t st) {
 #define VCT_LAUNCH(BM_, BN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
-  if (bm == 128 && bn == 128) VCT_LAUNCH(128, 128);
+  if (p.waves8) {   // many-wave variants (experiments + the big-GEMM default): waves8 = variant id
+    if constexpr (NBUF == 2) {
+#define VCT_LW(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, 2, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
+      // measured (tools/gemm_bench.py): 16-wave 128x128 / 256x128 and 8-wave 64x64 lose to these two everywhere
+      if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);
+      else if (p.waves8 == 4 && bm == 128 && bn == 64) VCT_LW(128, 64, 4, 2);
+      else return VCT_E_SHAPE;
+#undef VCT_LW
+    } else return VCT_E_SHAPE;
+  }
+  else if (bm == 128 && bn == 128) VCT_LAUNCH(128, 128);
   else if (bm == 128 && bn == 64) VCT_LAUNCH(128, 64);
   else if (bm == 64 && bn == 128) VCT_LAUNCH(64, 128);
   else if (bm == 64 && bn == 64) VCT_LAUNCH(64, 64);

@@ -20,6 +20,7 @@ struct GemmP {
   float* bias_grad;
   float* partial;       // != nullptr: split-K mode, raw accumulators to partial[z][M*N]
   float* bias_partial;  // split-K mode: [z][M]
+  int waves8;           // 128x128 tile with 8 waves (2x4) instead of 4 (2x2)
 };
 
 }  // namespace vct
