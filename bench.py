@@ -196,7 +196,7 @@ def main():
                        "hipgraph_step": bool(trainer.use_graph)},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),
-            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd (vct_gemm NT bf16, 64x128 tiles)",
+            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd 4864x30522x512 (gemm_bf16_v2_kernel NT, 128x128 tile, 8 waves, LDS-DMA double buffer)",
                                                      "gen_dx": "generator dX GEMM (vct_gemm NN)",
                                                      "gen_dw": "generator dW GEMM (vct_gemm TN)"}[dom],
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

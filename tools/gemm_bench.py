@@ -58,13 +58,13 @@ def run(name, ta, tb, M, N, K, odt, tile, iters=20):
 
 if __name__ == "__main__":
     sel = sys.argv[1:]
-    print(f"{'shape':30s} nbuf " + " ".join(f"{t:>15s}" for t in ["auto", "128x128w8", "128x64w8", "64x64"]))
+    print(f"{'shape':30s} nbuf " + " ".join(f"{t:>15s}" for t in ["128x128w8", "128x64w8", "64x64"]))
     for s in SHAPES:
         if sel and not any(x in s[0] for x in sel):
             continue
-        for nbuf in (2,):
+        for nbuf in (1, 2):
             row = []
-            for tile in (0, 5, 8, 4):
+            for tile in (5, 8, 4):
                 ms, tf = run(*s, tile + 10 * nbuf)
                 row.append(f"{ms*1e3:7.1f}us {tf:4.0f}TF")
             print(f"{s[0]:30s} {nbuf:4d} " + " ".join(f"{r:>15s}" for r in row), flush=True)

@@ -368,8 +368,8 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
     int pick = 3;
     const int tsel = d->reserved % 10;
     pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
-    if (tsel == 5) { pick = 0; pl.waves8 = 1; pl.nbuf = 2; }        // 128x128, 8 waves
-    else if (tsel == 8) { pick = 1; pl.waves8 = 4; pl.nbuf = 2; }   // 128x64, 8 waves
+    if (tsel == 5) { pick = 0; pl.waves8 = 1; }        // 128x128, 8 waves
+    else if (tsel == 8) { pick = 1; pl.waves8 = 4; }   // 128x64, 8 waves
     else if (tsel >= 1 && tsel <= 4) pick = tsel - 1;
     else {
       // measured on MI355X (tools/gemm_bench.py, cfg-B shapes).  The kernel is bound by the rate at which a CU

@@ -354,15 +354,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
 template <typename TO, int TA, int TB, int NBUF>
 static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t st) {
 #define VCT_LAUNCH(BM_, BN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
-  if (p.waves8) {   // many-wave variants (experiments + the big-GEMM default): waves8 = variant id
-    if constexpr (NBUF == 2) {
-#define VCT_LW(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, 2, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
-      // measured (tools/gemm_bench.py): 16-wave 128x128 / 256x128 and 8-wave 64x64 lose to these two everywhere
-      if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);
-      else if (p.waves8 == 4 && bm == 128 && bn == 64) VCT_LW(128, 64, 4, 2);
-      else return VCT_E_SHAPE;
+  if (p.waves8) {   // eight-wave variants: waves8 = variant id
+#define VCT_LW(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
+    // measured (tools/gemm_bench.py): 16-wave 128x128 / 256x128 and 8-wave 64x64 lose to these two everywhere
+    if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);
+    else if (p.waves8 == 4 && bm == 128 && bn == 64) VCT_LW(128, 64, 4, 2);
+    else return VCT_E_SHAPE;
 #undef VCT_LW
-    } else return VCT_E_SHAPE;
   }
   else if (bm == 128 && bn == 128) VCT_LAUNCH(128, 128);
   else if (bm == 128 && bn == 64) VCT_LAUNCH(128, 64);
