@@ -101,14 +101,21 @@ __device__ __forceinline__ float red16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ bool key_masked(const AttnP& p, const uint8_t* kp_row, int qq, int kk) {
-  return kk >= p.Lk || (p.causal && kk > qq) || (kp_row != nullptr && kp_row[kk] != 0);
+// padmask: bit k set = key k is padded (built once per wave with a ballot over kp_row[lane]; a per-element
+// byte load here would be a chain of dependent global loads inside the unrolled score loops)
+__device__ __forceinline__ bool key_masked(const AttnP& p, unsigned long long padmask, int qq, int kk) {
+  return kk >= p.Lk || (p.causal && kk > qq) || ((padmask >> kk) & 1ull);
+}
+__device__ __forceinline__ unsigned long long load_padmask(const uint8_t* kp_row, int Lk, int lane) {
+  if (kp_row == nullptr) return 0ull;
+  const uint8_t v = kp_row[min(lane, Lk - 1)];
+  return __ballot(lane < Lk && v != 0);
 }
 
 // S^T tiles for query tile qt:  st[t][r] = scale * Q[q = qt*16 + i] . K[key = t*16 + g*4 + r]   (masked -> -inf)
 template <typename T, int DT>
 __device__ __forceinline__ void scores_T(f32x4 (&st)[4], const T* Ks, const T* Qs, int qt, int LKT, int hd4, float scale,
-                                         const AttnP& p, const uint8_t* kp_row, int lane) {
+                                         const AttnP& p, unsigned long long kp_row, int lane) {
   using C = AttnCfg<T, DT>;
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
   stage_rows<T, DT>(Ks, kg, p.ldk, p.Lk, p.hd, RK, lane);
   stage_rows<T, DT>(Vs, vg, p.ldv, p.Lk, p.hd, RK, lane);
   __syncthreads();
-  const uint8_t* kp_row = p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr;
+  const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   const float scale = 1.0f / sqrtf((float)p.hd);
   const int hd4 = (p.hd + 3) / 4;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
   stage_rows<T, DT>(Ks, kg, p.ldk, p.Lk, p.hd, RK, lane);
   stage_rows<T, DT>(Vs, vg, p.ldv, p.Lk, p.hd, RK, lane);
   __syncthreads();
-  const uint8_t* kp_row = p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr;
+  const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   const float scale = 1.0f / sqrtf((float)p.hd);
   const int hd4 = (p.hd + 3) / 4;
