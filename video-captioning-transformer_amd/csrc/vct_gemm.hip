@@ -1,17 +1,17 @@
-// MFMA GEMM family for gfx950:  C[M,N] = epilogue(op(A)[M,K] * op(B)[K,N])
+// GEMM entry point of the C ABI (vct_gemm): planning (tile / wave / split-K choice), dispatch and the
+// fp32 PARITY-MODE kernel.  C[M,N] = epilogue(op(A)[M,K] * op(B)[K,N]).
 //
-//  * bf16 inputs : v_mfma_f32_16x16x32_bf16, BK = 64.  K-contiguous operands are staged to LDS as
-//    [rows][BK+8] and read as one ds_read_b128 fragment; operands whose contiguous dimension is the
-//    NON-reduced one (A of dW = dY^T X, B of dX = dY W) are staged as [BK][rows+16] and read with the
-//    gfx950 LDS transpose read (ds_read_b64_tr_b16) -- no transposed copies in HBM, no 2-byte LDS
-//    scatter.
-//  * f32 inputs  : v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), BK = 16, the tight-parity mode.
-//  * 256-thread workgroups (4 waves as 2x2), tile 128x128 or 64x64, register prefetch of the next
-//    K tile while the current one is in the matrix pipe, optional split-K with a deterministic
-//    second-pass reduce (weight gradients: tiny outputs, long K = tokens).
-//  * fused epilogues: bias, GELU/ReLU (+ saving the pre-activation), counter-hash dropout,
-//    residual-gradient accumulate, activation-derivative multiply, bias gradient (row sums of op(A)
-//    via one extra MFMA against a ones fragment).
+//  * bf16 inputs (throughput mode) go to gemm_bf16_v2_kernel (vct_gemm_bf16_kernel.h: LDS-DMA double buffer,
+//    swizzled LDS images, LDS transpose reads, 4- or 8-wave tiles).
+//  * f32 inputs: the kernel below -- v_mfma_f32_16x16x4_f32 (an exact fp32 fma chain), BK = 16, 256-thread
+//    workgroups (2x2 waves), tile 128x128 or 64x64, register-staged prefetch of the next K tile.  Operands whose
+//    contiguous dimension is the non-reduced one (A of dW = dY^T X, B of dX = dY W) are transposed while being
+//    written to LDS, so the compute loop is layout independent.  Performance is secondary here: this mode exists
+//    for <= 1e-3 parity with the CPU reference and bit-exact greedy-decode ids.
+//  * both share the fused epilogue (bias, GELU/ReLU + saved pre-activation, counter-hash dropout, residual-gradient
+//    accumulate, activation-derivative multiply, bias gradient via one extra MFMA against a ones fragment) staged
+//    through a per-wave fp32 LDS transpose so that every lane stores 16 contiguous bytes, and the deterministic
+//    split-K second pass (splitk_reduce_kernel).
 #include <cstdlib>
 #include "vct_common.h"
 #include "vct_gemm_params.h"
@@ -19,7 +19,6 @@
 namespace vct {
 
 template <typename TI> struct GemmCfg;
-template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8, KPAD = 8; };
 template <> struct GemmCfg<float> { static constexpr int BK = 16, VEC = 4, KPAD = 4; };
 
 // one global->register vector (16 bytes) ---------------------------------------------------------
@@ -27,9 +26,7 @@ struct alignas(16) Vec16 { uint32_t w[4]; };
 __device__ __forceinline__ Vec16 vec_zero() { Vec16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u; return v; }
 
 // Operand staging.  KC = stored [rows][K] (K contiguous); MC = stored [K][rows] (rows contiguous).
-// R = rows of the tile (BM or BN).  LDS images:
-//   bf16 KC : [R][BK+8]      bf16 MC : [BK][R+16]  (read by ds_read_b64_tr_b16)
-//   f32  KC : [R][BK+4]      f32  MC : transposed while storing into the same [R][BK+4] image
+// R = rows of the tile (BM or BN).  LDS image [R][BK+4] fp32 in both cases (MC is transposed while storing).
 template <typename TI, bool MC, int R>
 struct Stager {
   using Cfg = GemmCfg<TI>;
@@ -37,8 +34,7 @@ struct Stager {
   static constexpr bool BF = sizeof(TI) == 2;
   static constexpr int NV = (R * BK / VEC) / 256;  // vectors per thread
   static constexpr int KC_STRIDE = BK + Cfg::KPAD;
-  static constexpr int MC_STRIDE = R + 16;
-  static constexpr int LDS_ELEMS = (BF && MC) ? BK * MC_STRIDE : R * KC_STRIDE;
+  static constexpr int LDS_ELEMS = R * KC_STRIDE;
   static_assert(NV >= 1, "tile too small for 256 threads");
 
   // r_ext: valid rows; K: valid reduction length; reads along the contiguous dim are predicated per
@@ -71,10 +67,6 @@ struct Stager {
         constexpr int VPR = BK / VEC;
         const int row = v / VPR, kc = (v % VPR) * VEC;
         *reinterpret_cast<Vec16*>(lds + row * KC_STRIDE + kc) = regs[i];
-      } else if constexpr (BF) {
-        constexpr int VPR = R / VEC;
-        const int krow = v / VPR, rc = (v % VPR) * VEC;
-        *reinterpret_cast<Vec16*>(lds + krow * MC_STRIDE + rc) = regs[i];
       } else {
         constexpr int VPR = R / VEC;
         const int krow = v / VPR, rc = (v % VPR) * VEC;
@@ -85,41 +77,12 @@ struct Stager {
   }
 };
 
-// fragment fetch for one 16-row MFMA tile starting at tile row `r_base` --------------------------
-// bf16: returns the 8 k-values this lane owns for k-step `ks` (32 wide).  KSPLIT selects the k-slot
-// mapping {g*4+j, 16+g*4+j} instead of {g*8+j}; both operands of a TN product use it so the two
-// transpose reads of lanes 0..31 cover 8 consecutive LDS rows (bank-conflict free).
-template <bool MC, int R, bool KSPLIT>
-__device__ __forceinline__ bf16x8 frag_bf16(const bf16_t* lds, int r_base, int ks, int lane) {
-  using S = Stager<bf16_t, MC, R>;
-  const int i = lane & 15, g = lane >> 4;
-  if constexpr (!MC) {
-    if constexpr (!KSPLIT) {
-      return *reinterpret_cast<const bf16x8*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + g * 8);
-    } else {
-      const s16x4 lo = *reinterpret_cast<const s16x4*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + g * 4);
-      const s16x4 hi = *reinterpret_cast<const s16x4*>(lds + (r_base + i) * S::KC_STRIDE + ks * 32 + 16 + g * 4);
-      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      return __builtin_bit_cast(bf16x8, v);
-    }
-  } else {
-    const int kb1 = ks * 32 + (KSPLIT ? g * 4 : g * 8);
-    const int kb2 = KSPLIT ? ks * 32 + 16 + g * 4 : kb1 + 4;
-    const int col = r_base + (i & 3) * 4;
-    const s16x4 lo = lds_tr16(lds + (kb1 + (i >> 2)) * S::MC_STRIDE + col);
-    const s16x4 hi = lds_tr16(lds + (kb2 + (i >> 2)) * S::MC_STRIDE + col);
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-  }
-}
-
 template <typename TI, typename TO, int TA, int TB, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   using Cfg = GemmCfg<TI>;
   constexpr bool BF = sizeof(TI) == 2;
   constexpr int BK = Cfg::BK;
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
-  constexpr bool KSPLIT = BF && A_MC && B_MC;
   using SA = Stager<TI, A_MC, BM>;
   using SB = Stager<TI, B_MC, BN>;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
@@ -167,27 +130,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       SA::load(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K);
       SB::load(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K);
     }
-    if constexpr (BF) {
-#pragma unroll
-      for (int ks = 0; ks < BK / 32; ks++) {
-        bf16x8 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = frag_bf16<A_MC, BM, KSPLIT>(lds_a, wm * WM + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = frag_bf16<B_MC, BN, KSPLIT>(lds_b, wn * WN + j * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (do_bias_grad) {
-          const s16x8 o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-          const bf16x8 ones = __builtin_bit_cast(bf16x8, o);
-#pragma unroll
-          for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
-        }
-      }
-    } else {
+    {
+      static_assert(!BF, "bf16 inputs use gemm_bf16_v2_kernel");
       const float* la = reinterpret_cast<const float*>(lds_a);
       const float* lb = reinterpret_cast<const float*>(lds_b);
       const int i16 = lane & 15, g = lane >> 4;

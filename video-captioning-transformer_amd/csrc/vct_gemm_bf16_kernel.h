@@ -117,7 +117,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int STG_STRIDE = WN + 4;
   constexpr int STG_BYTES = NW * 16 * STG_STRIDE * 4;
-  constexpr int NDMA = (BM + BN) * 8 / NT;               // DMA instructions per K tile per wave
   static_assert(NBUF * BUF_BYTES >= STG_BYTES, "staging must fit");
   __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[NBUF * BUF_BYTES];
 
@@ -202,8 +201,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
     }
   };
   // NBUF = 1: stage -> wait -> barrier -> compute -> barrier (smallest LDS, most workgroups per CU)
-  // NBUF = 2: next tile's DMA flies under the MFMAs, one barrier per tile
-  // NBUF = 3: two tiles in flight, counted vmcnt + raw s_barrier (the DMA queue is never drained)
+  // NBUF = 2: next tile's DMA flies under the MFMAs, one barrier per tile (default)
+  // (a 3-deep ring with counted vmcnt + raw s_barrier was measured slower at every shape: it costs occupancy and
+  //  the kernel is bound by the per-CU fetch rate, not by exposed DMA latency)
   if constexpr (NBUF == 1) {
     for (int kt = kt_begin; kt < kt_end; kt++) {
       if (kt > kt_begin) __syncthreads();             // everyone finished reading the buffer
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
       __syncthreads();                                // DMA landed (vmcnt(0)) for everyone
       compute(lds_raw, lds_raw + A_BYTES);
     }
-  } else if constexpr (NBUF == 2) {
+  } else {
+    static_assert(NBUF == 2, "NBUF is 1 or 2");
     if (kt_begin < kt_end) stage(kt_begin, 0);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; kt++) {
@@ -219,20 +220,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
       compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES);
       cur ^= 1;
-    }
-  } else {
-    if (kt_begin < kt_end) stage(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; kt++) {
-      if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
-      compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES);
-      cur = cur == 2 ? 0 : cur + 1;
     }
   }
 
