@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 1
+#define VCT_ABI_VERSION 2
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -72,10 +72,29 @@ typedef struct vct_gemm_desc {
   void* workspace; int64_t workspace_bytes; /* split-K partials (fp32); NULL = never split */
   int32_t split_k;                          /* 0 auto, 1 none, >1 forced */
   int32_t reserved;
+  int32_t n_tile_counters;                  /* ints available at tile_counters */
+  int32_t* tile_counters;                   /* optional, see below */
 } vct_gemm_desc;
+/* tile_counters: device ints that are ZERO on entry (they are zero again when the GEMM has finished, so one
+ * zero-filled allocation serves every later call on the same stream).  With them a split-K GEMM reduces inside
+ * the producing kernel -- the last workgroup to finish a tile sums the partials in fixed split order
+ * (bit-reproducible) -- instead of in a second launch.  Needs one int per output tile (<= M*N/4096 + M/64 + N/64
+ * + 1 is always enough); without (NULL / too few) the two-pass reduce is used.  GEMMs that may run CONCURRENTLY
+ * (different streams) must not share counters or workspace. */
 int vct_gemm(const vct_gemm_desc* d, void* stream);
 /* bytes of workspace vct_gemm may use for this descriptor (0 if it will not split) */
 int64_t vct_gemm_workspace_bytes(const vct_gemm_desc* d);
+
+/* n (<= VCT_GEMM_GROUP_MAX) independent weight-gradient GEMMs in ONE launch: every descriptor must be the dW form
+ * (dtype bf16, out fp32, ta=1, tb=0, no epilogue other than bias_grad).  replaces: the per-Linear
+ * `grad_weight = grad_out.t() @ input` / `grad_bias = grad_out.sum(0)` autograd nodes of one Transformer layer
+ * (torch autograd of F.linear as used by nn.TransformerEncoderLayer / DecoderLayer, MMEncoder.py:236,
+ * CapDecoder.py:18), which the reference runs as 8-14 separate kernels per layer.
+ * Each descriptor carries its OWN workspace (vct_gemm_grouped_workspace_bytes(descs, n, i) bytes) and its OWN
+ * tile_counters (required whenever that is non-zero); split_k: 0 auto, >=1 forced. */
+#define VCT_GEMM_GROUP_MAX 8
+int vct_gemm_grouped(const vct_gemm_desc* descs, int32_t n, void* stream);
+int64_t vct_gemm_grouped_workspace_bytes(const vct_gemm_desc* descs, int32_t n, int32_t i);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention core: O = softmax(Q K^T / sqrt(hd) + mask) V per (batch, head), one wave each,

@@ -56,8 +56,62 @@ def run(name, ta, tb, M, N, K, odt, tile, iters=20):
     return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
 
 
+def vendor(name, ta, tb, M, N, K, odt, iters=20):
+    """torch.matmul (hipBLASLt / rocBLAS) on the same shape: yardstick only"""
+    a = torch.randn((K, M) if ta else (M, K), device=DEV).bfloat16()
+    b = torch.randn((N, K) if tb else (K, N), device=DEV).bfloat16()
+    f = lambda: (a.t() if ta else a) @ (b.t() if tb else b)
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
+
+
+def grouped(rows, mem_rows, splits=(0, 1, 2, 3), iters=20):
+    """a decoder / encoder layer's weight gradients as one grouped launch"""
+    from vct_amd import ops
+    dec = [(1536, 512, rows), (512, 512, rows), (512, 512, rows), (1024, 512, mem_rows), (512, 512, rows), (2048, 512, rows), (512, 2048, rows)]
+    enc = [(1536, 512, mem_rows), (512, 512, mem_rows), (2048, 512, mem_rows), (512, 2048, mem_rows)]
+    scratch = ops.GemmScratch(DEV, 256 << 20)
+    for name, shp in (("dec layer", dec), ("enc layer", enc)):
+        items = []
+        fl = 0.0
+        for M, N, r in shp:
+            dy = torch.randn(r, M, device=DEV).bfloat16(); x = torch.randn(r, N, device=DEV).bfloat16()
+            items.append((dy, x, torch.empty(M, N, device=DEV), torch.empty(M, device=DEV)))
+            fl += 2.0 * M * N * r
+        for tile in (0, 5, 8, 4):
+          for sp in splits:
+            for _ in range(3):
+                ops.gemm_grouped(items, scratch, split_k=sp, tile=tile)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(iters):
+                ops.gemm_grouped(items, scratch, split_k=sp, tile=tile)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            print(f"grouped {name} tile={tile} split={sp}: {ms*1e3:7.1f} us {fl/(ms*1e-3)/1e12:5.0f} TF", flush=True)
+
+
 if __name__ == "__main__":
     sel = sys.argv[1:]
+    if sel and sel[0] == "--grouped":
+        grouped(4864, 3328)
+        sys.exit(0)
+    if sel and sel[0] == "--auto":   # the plan the library picks by itself vs the vendor library
+        print(f"{'shape':30s} {'auto':>15s} {'vendor':>15s}")
+        for s in SHAPES:
+            ms, tf = run(*s, 0)
+            vm, vt = vendor(*s)
+            print(f"{s[0]:30s} {ms*1e3:7.1f}us {tf:4.0f}TF {vm*1e3:7.1f}us {vt:4.0f}TF", flush=True)
+        sys.exit(0)
     print(f"{'shape':30s} nbuf " + " ".join(f"{t:>15s}" for t in ["128x128w8", "128x64w8", "64x64"]))
     for s in SHAPES:
         if sel and not any(x in s[0] for x in sel):

@@ -9,6 +9,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 2
+GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
         -3: "VCT_E_ALIGN (leading dimension / alignment)", -4: "VCT_E_WORKSPACE (workspace too small)"}
@@ -21,7 +23,8 @@ class GemmDesc(C.Structure):
                 ("act", i32), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
                 ("bias", vp), ("preact", vp), ("ld_preact", i64), ("addend", vp), ("ld_addend", i64),
                 ("dact_src", vp), ("ld_dact", i64), ("seed", vp), ("site", u32), ("p_drop", f32),
-                ("bias_grad", vp), ("workspace", vp), ("workspace_bytes", i64), ("split_k", i32), ("reserved", i32)]
+                ("bias_grad", vp), ("workspace", vp), ("workspace_bytes", i64), ("split_k", i32), ("reserved", i32),
+                ("n_tile_counters", i32), ("tile_counters", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -37,6 +40,8 @@ _SIGS = {
     "vct_build_info": (C.c_int, [C.c_char_p, C.c_int]),
     "vct_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "vct_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
+    "vct_gemm_grouped": (C.c_int, [C.POINTER(GemmDesc), i32, vp]),
+    "vct_gemm_grouped_workspace_bytes": (i64, [C.POINTER(GemmDesc), i32, i32]),
     "vct_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
@@ -80,7 +85,7 @@ def load():
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-    if lib.vct_abi_version() != 1:
+    if lib.vct_abi_version() != ABI_VERSION:
         raise RuntimeError("libvct_hip.so ABI version mismatch")
     # one HIP runtime per process: our kernels must launch on torch's streams
     try:

@@ -308,7 +308,7 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   pl.nkt = (d->K + BK - 1) / BK;
   auto tiles = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
   if (bf) {
-    static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     int pick = 3;
     const int tsel = d->reserved % 10;
     pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
@@ -373,14 +373,21 @@ int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn
 
 using namespace vct;
 
-extern "C" int64_t vct_gemm_workspace_bytes(const vct_gemm_desc* d) {
-  if (d == nullptr) return 0;
-  const Plan pl = gemm_plan(d, true);
+// workspace layout: [split x M x N partials][split x M bias partials]
+static bool use_counters(const vct_gemm_desc* d, const Plan& pl) {
+  return d->tile_counters != nullptr && d->dtype == VCT_BF16 && (long)pl.tiles_m * pl.tiles_n <= (long)d->n_tile_counters;
+}
+static int64_t ws_bytes(const vct_gemm_desc* d, const Plan& pl) {
   if (pl.split <= 1) return 0;
   return (int64_t)pl.split * ((int64_t)d->M * d->N + d->M) * 4;
 }
 
-extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
+extern "C" int64_t vct_gemm_workspace_bytes(const vct_gemm_desc* d) {
+  if (d == nullptr) return 0;
+  return ws_bytes(d, gemm_plan(d, true));
+}
+
+static int check_desc(const vct_gemm_desc* d) {
   if (d == nullptr || d->A == nullptr || d->B == nullptr || d->C == nullptr) return VCT_E_ARG;
   if (d->dtype != VCT_F32 && d->dtype != VCT_BF16) return VCT_E_ARG;
   if (d->out_dtype != VCT_F32 && d->out_dtype != VCT_BF16) return VCT_E_ARG;
@@ -390,14 +397,10 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   if (d->lda % vec || d->ldb % vec) return VCT_E_ALIGN;
   if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return VCT_E_ALIGN;
   if (d->dact_src != nullptr && d->act == VCT_ACT_NONE) return VCT_E_ARG;  // dact needs the activation kind
-  hipStream_t st = (hipStream_t)stream;
+  return VCT_OK;
+}
 
-  const int64_t need = vct_gemm_workspace_bytes(d);
-  const bool have_ws = d->workspace != nullptr && d->workspace_bytes >= need && need > 0;
-  if (d->split_k > 1 && !have_ws) return VCT_E_WORKSPACE;
-  const Plan pl = gemm_plan(d, have_ws);
-
-  GemmP p;
+static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -412,12 +415,28 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   p.dact = d->dact_src; p.ld_dact = d->ld_dact;
   p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
   p.bias_grad = d->bias_grad;
-  p.partial = nullptr; p.bias_partial = nullptr;
+  p.partial = nullptr; p.bias_partial = nullptr; p.counters = nullptr;
   p.waves8 = pl.waves8;
+  p.split = pl.split;
   if (pl.split > 1) {
+    if (use_counters(d, pl)) p.counters = d->tile_counters;
     p.partial = reinterpret_cast<float*>(d->workspace);
     p.bias_partial = p.partial + (size_t)pl.split * d->M * d->N;
   }
+}
+
+extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
+  const int ok = check_desc(d);
+  if (ok != VCT_OK) return ok;
+  hipStream_t st = (hipStream_t)stream;
+
+  const int64_t need = vct_gemm_workspace_bytes(d);
+  const bool have_ws = d->workspace != nullptr && d->workspace_bytes >= need && need > 0;
+  if (d->split_k > 1 && !have_ws) return VCT_E_WORKSPACE;
+  const Plan pl = gemm_plan(d, have_ws);
+
+  GemmP p;
+  fill_params(d, pl, p);
   const dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
   int rc;
   if (d->dtype == VCT_BF16) {
@@ -428,7 +447,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   }
   if (rc != VCT_OK) return rc;
   VCT_CHECK_LAUNCH();
-  if (pl.split > 1) {
+  if (pl.split > 1 && p.counters == nullptr) {   // two-pass split-K (no tile counters given)
     const size_t total = (size_t)d->M * d->N;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (d->out_dtype == VCT_F32)
@@ -439,5 +458,85 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
                          reinterpret_cast<bf16_t*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
     VCT_CHECK_LAUNCH();
   }
+  return VCT_OK;
+}
+
+// ---- grouped weight-gradient launch --------------------------------------------------------------
+namespace vct {
+int gemm_bf16_v2_grouped_tn(const GemmGroupP& g, int bm, int bn, int total_wg, hipStream_t st);
+}
+
+// One tile shape for the whole group and a split per problem: a layer's weight gradients are 4-7 GEMMs with
+// 16-128 output tiles each -- launched one by one each leaves most of the chip idle and pays its own ramp-up and
+// split-K reduce.  descs[0].reserved overrides the tile for experiments (same codes as vct_gemm: 5, 8, 4).
+struct GroupTile { int bm, bn, waves8; };
+static long group_tiles(const vct_gemm_desc* descs, int n, const GroupTile& t) {
+  long gt = 0;
+  for (int k = 0; k < n; k++) gt += (long)((descs[k].M + t.bm - 1) / t.bm) * ((descs[k].N + t.bn - 1) / t.bn);
+  return gt;
+}
+static GroupTile grouped_tile(const vct_gemm_desc* descs, int n) {
+  const int sel = descs[0].reserved % 10;
+  if (sel == 4) return GroupTile{64, 64, 0};
+  if (sel == 8) return GroupTile{128, 64, 4};
+  if (sel == 5) return GroupTile{128, 128, 1};
+  // measured (tools/gemm_bench.py --grouped, MI355X): a decoder layer (256 tiles of 128x128) 74 us with 128x128
+  // tiles vs 88 us with 64x64; an encoder layer (192 tiles) 49 us vs 42 us -- one big tile per CU only pays
+  // once (nearly) every CU gets one
+  const GroupTile big{128, 128, 1};
+  return group_tiles(descs, n, big) >= 224 ? big : GroupTile{64, 64, 0};
+}
+static Plan grouped_plan(const vct_gemm_desc* d, const GroupTile& t, long gt) {
+  Plan pl;
+  pl.bm = t.bm; pl.bn = t.bn; pl.nbuf = 2; pl.waves8 = t.waves8;
+  pl.nkt = (d->K + 63) / 64;
+  pl.tiles_m = (d->M + t.bm - 1) / t.bm;
+  pl.tiles_n = (d->N + t.bn - 1) / t.bn;
+  // measured (tools/gemm_bench.py --grouped): every extra split costs ~10 us of coherent partial traffic on a layer's
+  // worth of weight gradients, so split only when the group cannot give every CU a workgroup
+  int split = gt >= 192 ? 1 : (int)((255 + gt) / gt);
+  if (d->split_k >= 1) split = d->split_k;
+  if (split > pl.nkt / 4) split = pl.nkt / 4 > 0 ? pl.nkt / 4 : 1;
+  if (split < 1) split = 1;
+  pl.kt_per = (pl.nkt + split - 1) / split;
+  pl.split = (pl.nkt + pl.kt_per - 1) / pl.kt_per;
+  return pl;
+}
+
+extern "C" int64_t vct_gemm_grouped_workspace_bytes(const vct_gemm_desc* descs, int32_t n, int32_t i) {
+  if (descs == nullptr || n < 1 || n > VCT_GEMM_GROUP_MAX || i < 0 || i >= n) return 0;
+  const GroupTile t = grouped_tile(descs, n);
+  return ws_bytes(descs + i, grouped_plan(descs + i, t, group_tiles(descs, n, t)));
+}
+
+extern "C" int vct_gemm_grouped(const vct_gemm_desc* descs, int32_t n, void* stream) {
+  if (descs == nullptr || n < 1 || n > VCT_GEMM_GROUP_MAX) return VCT_E_ARG;
+  for (int i = 0; i < n; i++) {
+    const vct_gemm_desc* d = descs + i;
+    const int ok = check_desc(d);
+    if (ok != VCT_OK) return ok;
+    // the group kernel is the weight-gradient form: bf16 operands, dW[M,N] = A^T B, fp32 out, no epilogue but db
+    if (d->dtype != VCT_BF16 || d->out_dtype != VCT_F32 || d->ta != 1 || d->tb != 0 || !gemm_can_split(d)) return VCT_E_ARG;
+  }
+  const GroupTile t = grouped_tile(descs, n);
+  const long gt = group_tiles(descs, n, t);
+  GemmGroupP g;
+  g.n = n;
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    const vct_gemm_desc* d = descs + i;
+    const Plan pl = grouped_plan(d, t, gt);
+    if (pl.split > 1) {   // the grouped form always reduces in-kernel
+      if (!use_counters(d, pl)) return VCT_E_WORKSPACE;
+      if (d->workspace == nullptr || d->workspace_bytes < ws_bytes(d, pl)) return VCT_E_WORKSPACE;
+    }
+    fill_params(d, pl, g.p[i]);
+    g.start[i] = wg;
+    wg += (pl.tiles_m * pl.tiles_n * pl.split + 7) & ~7;
+  }
+  for (int i = n; i < VCT_GEMM_GROUP_MAX; i++) { g.start[i] = wg; g.p[i] = g.p[0]; }
+  const int rc = gemm_bf16_v2_grouped_tn(g, t.bm, t.bn, wg, (hipStream_t)stream);
+  if (rc != VCT_OK) return rc;
+  VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -92,6 +92,29 @@ __device__ __forceinline__ void tail_tile(unsigned char* lds, const bf16_t* __re
   }
 }
 
+// Split-K partials cross XCDs (each XCD has a private, mutually non-coherent L2): they are written and read with
+// agent-scope relaxed ATOMIC accesses (write-through / L2-bypassing `sc1` stores and loads) so that no workgroup
+// needs an agent-scope fence -- on a multi-XCD part that fence writes back and invalidates the whole L2.
+__device__ __forceinline__ void coherent_store2(float* p, float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const f32x2 v = {a, b};
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_load2(const float* p, float& a, float& b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  const f32x2 v = __builtin_bit_cast(f32x2, u);
+  a = v[0]; b = v[1];
+}
+__device__ __forceinline__ void coherent_store1(float* p, float a) {
+  __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float coherent_load1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool MC, int R, bool KSPLIT>
 __device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, int ks, int lane) {
   const int i = lane & 15, g = lane >> 4;
@@ -108,8 +131,9 @@ __device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, in
   }
 }
 
-template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM = 2, int WGN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const GemmP p) {
+// One workgroup's tile of one GEMM: `bid` = workgroup index within the problem's tile grid, `zid` = K split.
+template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM, int WGN>
+__device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid, const int zid) {
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
   constexpr bool KSPLIT = A_MC && B_MC;
   constexpr int NW = WGM * WGN, NT = 64 * NW;         // waves / threads per workgroup
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
   const int nwg = p.tiles_m * p.tiles_n;
   int wgid;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int nkt = (p.K + BK2 - 1) / BK2;
-  const int kt_begin = blockIdx.z * p.kt_per_split;
+  const int kt_begin = zid * p.kt_per_split;
   const int kt_end = min(nkt, kt_begin + p.kt_per_split);
   const int kt_full_end = min(kt_end, p.K / BK2);   // tiles fully inside K go by DMA
 
@@ -226,13 +250,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
   // ---- epilogue (see vct_gemm.hip for the rationale of the per-wave LDS transpose) ---------------
   const int c16 = lane & 15, g4 = (lane >> 4) * 4;
   if (do_bias_grad && c16 == 0) {
-    float* bg = p.partial != nullptr ? p.bias_partial + (size_t)blockIdx.z * p.M : p.bias_grad;
+    float* bg = p.partial != nullptr ? p.bias_partial + (size_t)zid * p.M : p.bias_grad;
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = m0 + wm * WM + i * 16 + g4 + r;
-        if (row < p.M) bg[row] = accb[i][r];
+        if (row < p.M) {
+          if (p.counters != nullptr) coherent_store1(bg + row, accb[i][r]);
+          else bg[row] = accb[i][r];
+        }
       }
   }
   __syncthreads();
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
   TO* preact = reinterpret_cast<TO*>(p.preact);
   const TO* addend = reinterpret_cast<const TO*>(p.addend);
   const TO* dact = reinterpret_cast<const TO*>(p.dact);
-  float* partC = part ? p.partial + (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N : nullptr;
+  float* partC = part ? p.partial + (size_t)zid * (size_t)p.M * (size_t)p.N : nullptr;
   const long ldo = part ? (long)p.N : p.ldc;
   const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
   const bool lane_active = !CPL_PARTIAL || lane < 16 * CPR;
@@ -288,7 +315,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
       const bool full = vec_ok && (col + VO <= p.N);
       if (part) {
         float* dst = partC + (size_t)row * p.N + col;
-        if (full) {
+        if (p.counters != nullptr) {
+          if (full) {
+#pragma unroll
+            for (int q = 0; q < VO; q += 2) coherent_store2(dst + q, v[q], v[q + 1]);
+          } else {
+            for (int q = 0; q < VO; q++) if (col + q < p.N) coherent_store1(dst + q, v[q]);
+          }
+        } else if (full) {
 #pragma unroll
           for (int q = 0; q < VO; q += 4) *reinterpret_cast<f32x4*>(dst + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
         } else {
@@ -336,6 +370,87 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
       }
     });
   });
+
+  // ---- single-pass split-K: the LAST workgroup to finish a tile sums the partials in fixed z order ----
+  // (deterministic: the order of the additions does not depend on which workgroup arrives last).  The tile
+  // counters live in the caller's zero-initialised workspace head and are left zero again.
+  if (part && p.counters != nullptr) {
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's write-through partial stores have completed
+    __syncthreads();
+    if (tid == 0)
+      s_last = (__hip_atomic_fetch_add(p.counters + wgid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.split - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const size_t zstride = (size_t)p.M * (size_t)p.N;
+    static_for<TM>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      static_for<CPL>([&](auto CI) {
+        constexpr int c = decltype(CI)::value;
+        const int chunk = c * 64 + lane;
+        const int rr = (chunk / CPR) & 15, cc = (chunk % CPR) * VO;
+        const int row = m0 + wm * WM + i * 16 + rr, col = n0 + wn * WN + cc;
+        if (!lane_active || row >= p.M || col >= p.N) return;
+        const float* src = p.partial + (size_t)row * p.N + col;
+        const bool full = vec_ok && (col + VO <= p.N) && (p.ldc % VO == 0) && (((uintptr_t)p.C & 15) == 0);
+        float s[VO];
+#pragma unroll
+        for (int q = 0; q < VO; q++) s[q] = 0.0f;
+        if (full) {
+          for (int z = 0; z < p.split; z++) {
+#pragma unroll
+            for (int q = 0; q < VO; q += 2) {
+              float t0, t1;
+              coherent_load2(src + (size_t)z * zstride + q, t0, t1);
+              s[q] += t0; s[q + 1] += t1;
+            }
+          }
+          OutV ov;
+#pragma unroll
+          for (int q = 0; q < VO; q++) ov.e[q] = from_f<TO>(s[q]);
+          *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+        } else {
+          for (int q = 0; q < VO; q++) {
+            if (col + q >= p.N) break;
+            float a = 0.0f;
+            for (int z = 0; z < p.split; z++) a += coherent_load1(src + (size_t)z * zstride + q);
+            C[(size_t)row * p.ldc + col + q] = from_f<TO>(a);
+          }
+        }
+      });
+    });
+    if (p.bias_grad != nullptr && tile_n == 0) {
+      for (int r = tid; r < BM; r += NT) {
+        const int row = m0 + r;
+        if (row < p.M) {
+          float a = 0.0f;
+          for (int z = 0; z < p.split; z++) a += coherent_load1(p.bias_partial + (size_t)z * p.M + row);
+          p.bias_grad[row] = a;
+        }
+      }
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + wgid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next GEMM that uses this workspace
+  }
+}
+
+template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const GemmP p) {
+  gemm_bf16_v2_body<TO, TA, TB, BM, BN, NBUF, WGM, WGN>(p, blockIdx.x, blockIdx.z);
+}
+
+// Several independent GEMMs of the same layout / tile shape in ONE launch (a layer's weight gradients): the
+// workgroup looks its problem up in a by-value table; each problem's run of workgroups starts at a multiple of 8
+// so that `bid & 7` is still the XCD the hardware dispatches the workgroup to.
+template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_grouped_kernel(const GemmGroupP g) {
+  const int b = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < VCT_GEMM_GROUP_MAX; i++) gi = (i < g.n && b >= g.start[i]) ? i : gi;
+  const GemmP& p = g.p[gi];
+  const int local = b - g.start[gi], nwg = p.tiles_m * p.tiles_n;
+  if (local >= nwg * p.split) return;
+  gemm_bf16_v2_body<TO, TA, TB, BM, BN, NBUF, WGM, WGN>(p, local % nwg, local / nwg);
 }
 
 template <typename TO, int TA, int TB, int NBUF>
@@ -343,7 +458,8 @@ static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t s
 #define VCT_LAUNCH(BM_, BN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
   if (p.waves8) {   // eight-wave variants: waves8 = variant id
 #define VCT_LW(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
-    // measured (tools/gemm_bench.py): 16-wave 128x128 / 256x128 and 8-wave 64x64 lose to these two everywhere
+    // measured (tools/gemm_bench.py): 16-wave 128x128, 8-wave 64x64 and every 256-wide tile (256x256 with 8 or 16 waves,
+    // 256x128 with 8 waves, single or double buffered: 320-570 TF where 128x128 gives 550-780) lose to these two everywhere
     if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);
     else if (p.waves8 == 4 && bm == 128 && bn == 64) VCT_LW(128, 64, 4, 2);
     else return VCT_E_SHAPE;

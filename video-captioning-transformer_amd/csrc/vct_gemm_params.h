@@ -1,6 +1,7 @@
 // Kernel-side parameter block shared by the GEMM translation units.
 #pragma once
 #include <stdint.h>
+#include "../../include/vct_hip.h"
 
 namespace vct {
 
@@ -21,6 +22,14 @@ struct GemmP {
   float* partial;       // != nullptr: split-K mode, raw accumulators to partial[z][M*N]
   float* bias_partial;  // split-K mode: [z][M]
   int waves8;           // 128x128 tile with 8 waves (2x4) instead of 4 (2x2)
+  int split;            // number of K splits (gridDim.z of the single launch)
+  int* counters;        // != nullptr: per-tile arrival counters (zero on entry/exit): single-pass split-K
+};
+
+struct GemmGroupP {
+  int n;
+  int start[VCT_GEMM_GROUP_MAX];   // first workgroup of problem i (multiple of 8)
+  GemmP p[VCT_GEMM_GROUP_MAX];
 };
 
 }  // namespace vct

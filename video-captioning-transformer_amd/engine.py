@@ -116,6 +116,7 @@ class _StackBase:
         self.p_drop = 0.0
         self._ws = None
         self._ln_pending = []
+        self._dw_pending = []
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
     def W(self, k): return self.ps.c[self.pre + k]
@@ -126,32 +127,52 @@ class _StackBase:
         return (self.seed, site, self.p_drop) if self.p_drop > 0.0 else None
 
     def gemm_ws(self):
+        """Split-K scratch of the main stream (partials + zeroed tile counters)."""
         if self._ws is None:
-            self._ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.dev)
+            self._ws = ops.GemmScratch(self.dev)
         return self._ws
 
-    # ---- weight-gradient GEMMs on a side HIP stream ---------------------------------------------
-    # dW = dY^T X only depends on dY (just produced) and X (saved), and nothing downstream in backward
-    # reads it: it runs on a second stream beside the dX chain so two half-empty grids share the CUs.
+    # ---- weight-gradient GEMMs: grouped per layer, on a side HIP stream ---------------------------
+    # dW = dY^T X only depends on dY (produced by the dX chain) and X (saved), and nothing downstream in backward
+    # reads it.  A layer's 4-7 weight gradients are small (16-128 output tiles each): they are queued while the
+    # layer's dX chain runs and issued as ONE grouped launch (ops.gemm_grouped) on a second stream, where they
+    # overlap the next layer's dX chain.  The two big ones (generator) go out immediately, alone.
     overlap_dw = True
+    group_dw = True
     _side = None
     _side_ws = None
 
-    def dw_gemm(self, *args, **kw):
+    def _on_side(self, fn):
         if not (self.overlap_dw and self.dev.type == "cuda"):
-            return ops.gemm(*args, workspace=self.gemm_ws(), **kw)
+            return fn(self.gemm_ws())
         cls = _StackBase
         if cls._side is None:
             cls._side = torch.cuda.Stream(device=self.dev)
-            cls._side_ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.dev)
-        main = torch.cuda.current_stream()
-        cls._side.wait_stream(main)
+            cls._side_ws = ops.GemmScratch(self.dev)
+        cls._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cls._side):
-            ops.gemm(*args, workspace=cls._side_ws, **kw)
+            return fn(cls._side_ws)
+
+    def dw_gemm(self, dy, x, dw, *, bias_grad=None, m_valid=None, tag=None):
+        """dw[M,N] (fp32 gradient view) = dy^T x, bias_grad[M] = column sums of dy."""
+        if self.group_dw and m_valid is None and tag is None and dy.dtype == torch.bfloat16:
+            self._dw_pending.append((dy, x, dw, bias_grad))
+            if len(self._dw_pending) == ops.L.GEMM_GROUP_MAX:
+                self.flush_dw()
+            return
+        self._on_side(lambda ws: ops.gemm(dy, x, dw, ta=True, tb=False, bias_grad=bias_grad, m_valid=m_valid, tag=tag,
+                                          workspace=ws))
+
+    def flush_dw(self):
+        """Issue the queued weight-gradient GEMMs as one grouped launch."""
+        if self._dw_pending:
+            items, self._dw_pending = self._dw_pending, []
+            self._on_side(lambda ws: ops.gemm_grouped(items, ws))
 
     def join_side(self):
         """Main stream waits for every weight-gradient GEMM issued so far (before a gradient bucket is
         handed to the exchange / the optimizer)."""
+        self.flush_dw()
         if _StackBase._side is not None and self.overlap_dw:
             torch.cuda.current_stream().wait_stream(_StackBase._side)
 
@@ -193,7 +214,7 @@ class _StackBase:
         o = b.t[tag + "o"]
         d_o = b.get(tag + "d_o", (Mq, d), self.dt)
         ops.gemm(da, self.W(lp + "out_proj.weight"), d_o, ta=False, tb=False)
-        self.dw_gemm(da, o, self.G(lp + "out_proj.weight"), ta=True, tb=False, bias_grad=self.G(lp + "out_proj.bias"))
+        self.dw_gemm(da, o, self.G(lp + "out_proj.weight"), bias_grad=self.G(lp + "out_proj.bias"))
         dx = b.get(tag + "dx", (Mq, d), self.dt)
         if self_attn:
             qkv = b.t[tag + "qkv"]
@@ -201,7 +222,7 @@ class _StackBase:
             ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], d_o, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                          Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=self.drop(site))
             ops.gemm(dqkv, self.W(lp + "in_proj_weight"), dx, ta=False, tb=False, addend=ds_res)
-            self.dw_gemm(dqkv, x, self.G(lp + "in_proj_weight"), ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias"))
+            self.dw_gemm(dqkv, x, self.G(lp + "in_proj_weight"), bias_grad=self.G(lp + "in_proj_bias"))
         else:
             q, kv = b.t[tag + "q"], b.t[tag + "kv"]
             dq = b.get(tag + "dq", (Mq, d), self.dt)
@@ -209,10 +230,10 @@ class _StackBase:
             ops.attn_bwd(q, kv[:, :d], kv[:, d:], d_o, dq, dkv[:, :d], dkv[:, d:], Bn, H, Lq, Lk, causal=causal,
                          key_pad=key_pad, dropout=self.drop(site))
             ops.gemm(dq, self.W(lp + "in_proj_weight")[:d], dx, ta=False, tb=False, addend=ds_res)
-            self.dw_gemm(dq, x, self.G(lp + "in_proj_weight")[:d], ta=True, tb=False, bias_grad=self.G(lp + "in_proj_bias")[:d])
+            self.dw_gemm(dq, x, self.G(lp + "in_proj_weight")[:d], bias_grad=self.G(lp + "in_proj_bias")[:d])
             ops.gemm(dkv, self.W(lp + "in_proj_weight")[d:], dkv_out, ta=False, tb=False,
                      addend=dkv_out if dkv_accumulate else None)
-            self.dw_gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:], ta=True, tb=False,
+            self.dw_gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:],
                          bias_grad=self.G(lp + "in_proj_bias")[d:])
         return dx
 
@@ -268,10 +289,10 @@ class _StackBase:
         dhpre = b.get(tag + "dhpre", (M, ff), self.dt)
         ops.gemm(df, self.W(lp + "linear2.weight"), dhpre, ta=False, tb=False, act=self.cfg["activation"],
                  dact_src=b.t[tag + "hpre"], dropout=self.drop(site))
-        self.dw_gemm(df, b.t[tag + "h"], self.G(lp + "linear2.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear2.bias"))
+        self.dw_gemm(df, b.t[tag + "h"], self.G(lp + "linear2.weight"), bias_grad=self.G(lp + "linear2.bias"))
         dx = b.get(tag + "dxf", (M, d), self.dt)
         ops.gemm(dhpre, self.W(lp + "linear1.weight"), dx, ta=False, tb=False, addend=ds_res)
-        self.dw_gemm(dhpre, x, self.G(lp + "linear1.weight"), ta=True, tb=False, bias_grad=self.G(lp + "linear1.bias"))
+        self.dw_gemm(dhpre, x, self.G(lp + "linear1.weight"), bias_grad=self.G(lp + "linear1.bias"))
         return dx
 
 
@@ -340,12 +361,14 @@ class EncoderEngine(_StackBase):
             dx1 = self._ffn_bwd(b, tag + "ff.", lp, df, x1, site + 3, ds2)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
+            if l > 0:
+                self.flush_dw()           # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None and l > 0:
                 self.flush_ln_grads(b)
                 self.join_side()
                 bucket_ready("enc_layer", l)
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
-        self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), ta=True, tb=False, bias_grad=self.G("unify.0.bias"))
+        self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), bias_grad=self.G("unify.0.bias"))
         self.flush_ln_grads(b)
         self.join_side()
         if bucket_ready is not None:
@@ -424,7 +447,7 @@ class DecoderEngine(_StackBase):
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
         ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
-        self.dw_gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
+        self.dw_gemm(dl, y, self.G("generator.weight"), bias_grad=self.G("generator.bias"), m_valid=self.V,
                      tag="gen_dw")
         if bucket_ready is not None:
             self.join_side()
@@ -441,6 +464,7 @@ class DecoderEngine(_StackBase):
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+            self.flush_dw()               # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None:      # this layer's (and, for the top layer, the final norm's) gradients are complete
                 self.flush_ln_grads(b)
                 self.join_side()

@@ -24,16 +24,19 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = False, tb: bool = True,
-         bias: Optional[torch.Tensor] = None, act: Optional[str] = None, preact: Optional[torch.Tensor] = None,
-         addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
-         bias_grad: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, split_k: int = 0,
-         n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None,
-         tag: Optional[str] = None) -> torch.Tensor:
-    """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
-    tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
-    logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns)."""
-    lib = L.load()
+class GemmScratch:
+    """Split-K scratch of ONE stream: fp32 partials + the zero-initialised tile counters that let the split-K
+    reduction happen inside the producing kernel (include/vct_hip.h, tile_counters).  GEMMs that may run
+    concurrently must use different GemmScratch objects."""
+    COUNTERS_PER_SLOT = 16384
+
+    def __init__(self, device, nbytes: int = 64 << 20):
+        self.ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.counters = torch.zeros(L.GEMM_GROUP_MAX * self.COUNTERS_PER_SLOT, dtype=torch.int32, device=device)
+
+
+def _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
+               n_valid, k_valid, m_valid):
     d = L.GemmDesc()
     d.dtype, d.out_dtype = L.dtype_code(a.dtype), L.dtype_code(out.dtype)
     assert b.dtype == a.dtype
@@ -62,9 +65,28 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
         d.dact_src, d.ld_dact = dact_src.data_ptr(), _ld(dact_src)
     d.seed, d.site, d.p_drop = _drop(dropout)
     d.bias_grad = L.ptr(bias_grad)
-    if workspace is not None:
+    if isinstance(workspace, GemmScratch):
+        d.workspace, d.workspace_bytes = workspace.ws.data_ptr(), workspace.ws.numel() * 4
+        d.tile_counters, d.n_tile_counters = workspace.counters.data_ptr(), GemmScratch.COUNTERS_PER_SLOT
+    elif workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     d.split_k = split_k
+    return d
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = False, tb: bool = True,
+         bias: Optional[torch.Tensor] = None, act: Optional[str] = None, preact: Optional[torch.Tensor] = None,
+         addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
+         bias_grad: Optional[torch.Tensor] = None, workspace=None, split_k: int = 0,
+         n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None,
+         tag: Optional[str] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
+    tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
+    logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns).
+    workspace: a fp32 tensor (two-pass split-K) or a GemmScratch (single-pass split-K)."""
+    lib = L.load()
+    d = _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
+                   n_valid, k_valid, m_valid)
     tap = event_taps.get(tag) if tag is not None and event_taps else None
     if tap is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,6 +96,32 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
         e1.record()
         tap.append((e0, e1))
     return out
+
+
+def gemm_grouped(items, scratch: GemmScratch, split_k: int = 0, tile: int = 0):
+    """One launch for up to 8 weight-gradient GEMMs: items = [(dy [rows,M], x [rows,N], dW [M,N] fp32, db [M] fp32 or None)]
+    -> dW = dy^T x, db = column sums of dy (include/vct_hip.h, vct_gemm_grouped)."""
+    lib = L.load()
+    n = len(items)
+    if not 1 <= n <= L.GEMM_GROUP_MAX:
+        raise ValueError(f"gemm_grouped: 1..{L.GEMM_GROUP_MAX} problems per launch, got {n}")
+    arr = (L.GemmDesc * n)()
+    for i, (dy, x, dw, db) in enumerate(items):
+        d = _gemm_desc(dy, x, dw, True, False, None, None, None, None, None, None, db, None, split_k, None, None, None)
+        C_ = L.C
+        C_.memmove(C_.byref(arr[i]), C_.byref(d), C_.sizeof(L.GemmDesc))
+    arr[0].reserved = tile
+    off = 0
+    for i in range(n):
+        need = int(lib.vct_gemm_grouped_workspace_bytes(arr, n, i))
+        need = (need + 255) // 256 * 256
+        arr[i].workspace, arr[i].workspace_bytes = scratch.ws.data_ptr() + off, need
+        arr[i].tile_counters = scratch.counters.data_ptr() + 4 * i * GemmScratch.COUNTERS_PER_SLOT
+        arr[i].n_tile_counters = GemmScratch.COUNTERS_PER_SLOT
+        off += need
+    if off > scratch.ws.numel() * 4:
+        raise ValueError(f"gemm_grouped: scratch too small ({off} > {scratch.ws.numel() * 4} bytes)")
+    L.check(lib.vct_gemm_grouped(arr, n, L.stream_ptr()), "vct_gemm_grouped")
 
 
 def gemm_workspace_bytes(M: int, N: int, K: int, dtype: torch.dtype) -> int:
