@@ -40,32 +40,56 @@ template <typename T, int DT> struct AttnCfg {
   static constexpr int KS = BF ? HDK / 32 : 0;                  // bf16 k-steps over the head dim
 };
 
-// cooperative (one wave) copy of rows [0,L) x cols [0,hd) of a head slice into LDS, zero padded to
-// `rows_alloc` x HDK
+// cooperative (one wave) copy of rows [0,L) x cols [0,hd) of NJ head slices into LDS, each zero padded to
+// rows_alloc x HDK.  The 16-byte loads of ALL slices are issued back to back before the first LDS write (one
+// HBM/L2 round trip per wave instead of one per slice -- the wave has nothing else to overlap it with), and
+// UNCONDITIONALLY (row / column clamped into the slice, padding zeroed afterwards): a predicated load costs a
+// branch + vmcnt(0) per vector.
+struct alignas(16) AV16 { uint32_t w[4]; };
+template <typename T> struct StageJob { T* lds; const T* g; long ld; int L; int rows_alloc; };
+
 template <typename T, int DT>
-__device__ __forceinline__ void stage_rows(T* lds, const T* __restrict__ g, long ld, int L, int hd, int rows_alloc, int lane) {
+__device__ __forceinline__ void stage_load4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane) {
   using C = AttnCfg<T, DT>;
   constexpr int VPR = C::HDK / C::VEC;
-  struct alignas(16) V16 { uint32_t w[4]; };
-  const int total = rows_alloc * VPR;
-  // four 16-byte loads per lane are issued back to back, UNCONDITIONALLY (row / column clamped into the
-  // slice); padding is zeroed afterwards.  A predicated load here costs a branch + vmcnt(0) per vector.
-  for (int base = 0; base < total; base += 256) {
-    V16 val[4];
+  const int total = j.rows_alloc * VPR;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = min(base + u * 64 + lane, total - 1);
-      const int r = min(idx / VPR, L - 1), c = min((idx % VPR) * C::VEC, hd - C::VEC);
-      val[u] = *reinterpret_cast<const V16*>(g + (long)r * ld + c);
+  for (int u = 0; u < 4; u++) {
+    const int idx = min(base + u * 64 + lane, total - 1);
+    const int r = min(idx / VPR, j.L - 1), c = min((idx % VPR) * C::VEC, hd - C::VEC);
+    val[u] = *reinterpret_cast<const AV16*>(j.g + (long)r * j.ld + c);
+  }
+}
+template <typename T, int DT>
+__device__ __forceinline__ void stage_commit4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane) {
+  using C = AttnCfg<T, DT>;
+  constexpr int VPR = C::HDK / C::VEC;
+  const int total = j.rows_alloc * VPR;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int idx = base + u * 64 + lane;
+    if (idx < total) {
+      const int r = idx / VPR, c = (idx % VPR) * C::VEC;
+      if (r >= j.L || c >= hd) val[u].w[0] = val[u].w[1] = val[u].w[2] = val[u].w[3] = 0u;
+      *reinterpret_cast<AV16*>(j.lds + r * C::STR + c) = val[u];
     }
+  }
+}
+template <typename T, int DT, int NJ>
+__device__ __forceinline__ void stage_multi(const StageJob<T> (&jobs)[NJ], int hd, int lane) {
+  using C = AttnCfg<T, DT>;
+  constexpr int VPR = C::HDK / C::VEC;
+  AV16 val[NJ][4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = base + u * 64 + lane;
-      if (idx < total) {
-        const int r = idx / VPR, c = (idx % VPR) * C::VEC;
-        if (r >= L || c >= hd) val[u].w[0] = val[u].w[1] = val[u].w[2] = val[u].w[3] = 0u;
-        *reinterpret_cast<V16*>(lds + r * C::STR + c) = val[u];
-      }
+  for (int j = 0; j < NJ; j++) stage_load4<T, DT>(val[j], jobs[j], 0, hd, lane);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) stage_commit4<T, DT>(val[j], jobs[j], 0, hd, lane);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {       // slices with more than 256 vectors (long sequences / wide heads)
+    const int total = jobs[j].rows_alloc * VPR;
+    for (int base = 256; base < total; base += 256) {
+      stage_load4<T, DT>(val[0], jobs[j], base, hd, lane);
+      stage_commit4<T, DT>(val[0], jobs[j], base, hd, lane);
     }
   }
 }
@@ -90,6 +114,20 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
 #pragma unroll
   for (int j = 0; j < 4; j++) { v[j] = (short)f2bf(a[j]); v[4 + j] = (short)f2bf(b[j]); }
   return __builtin_bit_cast(bf16x8, v);
+}
+
+// Output tiles are produced TRANSPOSED (swap the MFMA operands: X^T = B^T A^T, and the per-lane register pattern of
+// an A fragment equals that of a B fragment): the C fragment then holds, per lane, ONE sequence row (lane & 15) and
+// FOUR consecutive head-dim columns ((lane >> 4) * 4 + r) -- one 8/16-byte store instead of four scattered 2/4-byte ones.
+template <typename T> struct alignas(4 * sizeof(T)) Out4 { T e[4]; };
+template <typename T>
+__device__ __forceinline__ void store_row4(T* base, long ld, int row, int col, const f32x4& v, int nrows, int hd) {
+  if (row < nrows && col < hd) {
+    Out4<T> o;
+#pragma unroll
+    for (int r = 0; r < 4; r++) o.e[r] = from_f<T>(v[r]);
+    *reinterpret_cast<Out4<T>*>(base + (long)row * ld + col) = o;
+  }
 }
 
 // reduce over the 4 lane groups that share (lane & 15): lanes l, l^16, l^32, l^48
@@ -156,9 +194,10 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
   const T* kg = reinterpret_cast<const T*>(p.k) + (long)b * p.k_bs + (long)h * p.hd;
   const T* vg = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)h * p.hd;
   T* og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)h * p.hd;
-  stage_rows<T, DT>(Qs, qg, p.ldq, p.Lq, p.hd, RQ, lane);
-  stage_rows<T, DT>(Ks, kg, p.ldk, p.Lk, p.hd, RK, lane);
-  stage_rows<T, DT>(Vs, vg, p.ldv, p.Lk, p.hd, RK, lane);
+  {
+    const StageJob<T> jobs[3] = {{Qs, qg, p.ldq, p.Lq, RQ}, {Ks, kg, p.ldk, p.Lk, RK}, {Vs, vg, p.ldv, p.Lk, RK}};
+    stage_multi<T, DT, 3>(jobs, p.hd, lane);
+  }
   __syncthreads();
   const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
@@ -201,7 +240,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
           const bf16x8 pa = pack_p(st[kp * 2], st[kp * 2 + 1]);
 #pragma unroll
           for (int dt = 0; dt < DT; dt++)
-            ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_colk<C::STR>(Vs, kp * 32, kp * 32 + 16, dt * 16, lane),
+            ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_colk<C::STR>(Vs, kp * 32, kp * 32 + 16, dt * 16, lane), pa,
                                                              ot[dt], 0, 0, 0);
         }
       }
@@ -213,17 +252,12 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
           for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int dt = 0; dt < DT; dt++)
-              ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[t][r], Vs[(t * 16 + g * 4 + r) * C::STR + dt * 16 + i], ot[dt], 0, 0, 0);
+              ot[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(t * 16 + g * 4 + r) * C::STR + dt * 16 + i], st[t][r], ot[dt], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int qo = qt * 16 + g * 4 + r, dc = dt * 16 + i;
-        if (qo < p.Lq && dc < p.hd) og[(long)qo * p.ldo + dc] = from_f<T>(ot[dt][r]);
-      }
+    for (int dt = 0; dt < DT; dt++) store_row4<T>(og, p.ldo, qt * 16 + i, dt * 16 + g * 4, ot[dt], p.Lq, p.hd);   // ot = O^T tile
   }
 }
 
@@ -249,10 +283,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
   T* dqg = reinterpret_cast<T*>(p.dq) + (long)b * p.Lq * p.ld_dq + (long)h * p.hd;
   T* dkg = reinterpret_cast<T*>(p.dk) + (long)b * p.Lk * p.ld_dk + (long)h * p.hd;
   T* dvg = reinterpret_cast<T*>(p.dv) + (long)b * p.Lk * p.ld_dv + (long)h * p.hd;
-  stage_rows<T, DT>(Qs, qg, p.ldq, p.Lq, p.hd, RQ, lane);
-  stage_rows<T, DT>(dOs, dog, p.ld_do, p.Lq, p.hd, RQ, lane);
-  stage_rows<T, DT>(Ks, kg, p.ldk, p.Lk, p.hd, RK, lane);
-  stage_rows<T, DT>(Vs, vg, p.ldv, p.Lk, p.hd, RK, lane);
+  {
+    const StageJob<T> jobs[4] = {{Qs, qg, p.ldq, p.Lq, RQ}, {dOs, dog, p.ld_do, p.Lq, RQ}, {Ks, kg, p.ldk, p.Lk, RK}, {Vs, vg, p.ldv, p.Lk, RK}};
+    stage_multi<T, DT, 4>(jobs, p.hd, lane);
+  }
   __syncthreads();
   const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
@@ -320,7 +354,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
           const bf16x8 pa = pack_p(st[kp * 2], st[kp * 2 + 1]);
 #pragma unroll
           for (int dt = 0; dt < DT; dt++)
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_colk<C::STR>(Ks, kp * 32, kp * 32 + 16, dt * 16, lane),
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_colk<C::STR>(Ks, kp * 32, kp * 32 + 16, dt * 16, lane), pa,
                                                               acc[dt], 0, 0, 0);
         }
       }
@@ -332,17 +366,12 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
           for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int dt = 0; dt < DT; dt++)
-              acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[t][r], Ks[(t * 16 + g * 4 + r) * C::STR + dt * 16 + i], acc[dt], 0, 0, 0);
+              acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(t * 16 + g * 4 + r) * C::STR + dt * 16 + i], st[t][r], acc[dt], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int qo = qt * 16 + g * 4 + r, dc = dt * 16 + i;
-        if (qo < p.Lq && dc < p.hd) dqg[(long)qo * p.ld_dq + dc] = from_f<T>(acc[dt][r]);
-      }
+    for (int dt = 0; dt < DT; dt++) store_row4<T>(dqg, p.ld_dq, qt * 16 + i, dt * 16 + g * 4, acc[dt], p.Lq, p.hd);   // acc = dQ^T tile
   }
   __syncthreads();  // stats visible
 
@@ -397,8 +426,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
           const bf16x8 da = pack_p(dsv[0], dsv[1]);
 #pragma unroll
           for (int dt = 0; dt < DT; dt++) {
-            av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_colk<C::STR>(dOs, qp * 32, qp * 32 + 16, dt * 16, lane), av[dt], 0, 0, 0);
-            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_colk<C::STR>(Qs, qp * 32, qp * 32 + 16, dt * 16, lane), ak[dt], 0, 0, 0);
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_colk<C::STR>(dOs, qp * 32, qp * 32 + 16, dt * 16, lane), pa, av[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_colk<C::STR>(Qs, qp * 32, qp * 32 + 16, dt * 16, lane), da, ak[dt], 0, 0, 0);
           }
         } else {
 #pragma unroll
@@ -408,23 +437,18 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
               const int qrow = (qp * 2 + u) * 16 + g * 4 + r;
 #pragma unroll
               for (int dt = 0; dt < DT; dt++) {
-                av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[u][r], dOs[qrow * C::STR + dt * 16 + i], av[dt], 0, 0, 0);
-                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[u][r], Qs[qrow * C::STR + dt * 16 + i], ak[dt], 0, 0, 0);
+                av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dOs[qrow * C::STR + dt * 16 + i], pd[u][r], av[dt], 0, 0, 0);
+                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[qrow * C::STR + dt * 16 + i], dsv[u][r], ak[dt], 0, 0, 0);
               }
             }
         }
       }
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ko = t * 16 + g * 4 + r, dc = dt * 16 + i;
-        if (ko < p.Lk && dc < p.hd) {
-          dvg[(long)ko * p.ld_dv + dc] = from_f<T>(av[dt][r]);
-          dkg[(long)ko * p.ld_dk + dc] = from_f<T>(ak[dt][r]);
-        }
-      }
+    for (int dt = 0; dt < DT; dt++) {   // av / ak = dV^T / dK^T tiles
+      store_row4<T>(dvg, p.ld_dv, t * 16 + i, dt * 16 + g * 4, av[dt], p.Lk, p.hd);
+      store_row4<T>(dkg, p.ld_dk, t * 16 + i, dt * 16 + g * 4, ak[dt], p.Lk, p.hd);
+    }
   }
 }
 
@@ -476,6 +500,11 @@ static int attn_common(const vct_attn_desc* d, bool bwd, void* stream) {
   const int vec = d->dtype == VCT_BF16 ? 8 : 4;
   if (d->hd % vec || d->ldq % vec || d->ldk % vec || d->ldv % vec) return VCT_E_ALIGN;
   if (bwd && (d->ld_do % vec)) return VCT_E_ALIGN;
+  // outputs are written four head-dim columns at a time
+  const uintptr_t omask = d->dtype == VCT_BF16 ? 7 : 15;
+  if (!bwd && ((d->ldo % 4) || ((uintptr_t)d->o & omask))) return VCT_E_ALIGN;
+  if (bwd && ((d->ld_dq % 4) || (d->ld_dk % 4) || (d->ld_dv % 4) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & omask)))
+    return VCT_E_ALIGN;
   AttnP p;
   p.B = d->B; p.H = d->H; p.Lq = d->Lq; p.Lk = d->Lk; p.hd = d->hd; p.causal = d->causal;
   p.q = d->q; p.ldq = d->ldq; p.k = d->k; p.ldk = d->ldk; p.v = d->v; p.ldv = d->ldv;

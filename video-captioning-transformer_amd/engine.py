@@ -169,6 +169,19 @@ class _StackBase:
             items, self._dw_pending = self._dw_pending, []
             self._on_side(lambda ws: ops.gemm_grouped(items, ws))
 
+    def bucket_on_side(self, bucket_ready, *args):
+        """Hand a finished gradient bucket to `bucket_ready` WITHOUT stalling the dX chain: the hook runs with the
+        side stream current, after that stream has been ordered behind everything enqueued so far on the main
+        stream -- an all-reduce issued from the hook waits for this bucket's weight gradients (side stream) and
+        LayerNorm/bias gradients (main stream) while the main stream goes straight on to the next layer."""
+        self.flush_dw()
+        side = _StackBase._side
+        if side is None or not self.overlap_dw:
+            return bucket_ready(*args)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            return bucket_ready(*args)
+
     def join_side(self):
         """Main stream waits for every weight-gradient GEMM issued so far (before a gradient bucket is
         handed to the exchange / the optimizer)."""
@@ -365,8 +378,7 @@ class EncoderEngine(_StackBase):
                 self.flush_dw()           # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None and l > 0:
                 self.flush_ln_grads(b)
-                self.join_side()
-                bucket_ready("enc_layer", l)
+                self.bucket_on_side(bucket_ready, "enc_layer", l)
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
         self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), bias_grad=self.G("unify.0.bias"))
         self.flush_ln_grads(b)
@@ -450,8 +462,7 @@ class DecoderEngine(_StackBase):
         self.dw_gemm(dl, y, self.G("generator.weight"), bias_grad=self.G("generator.bias"), m_valid=self.V,
                      tag="gen_dw")
         if bucket_ready is not None:
-            self.join_side()
-            bucket_ready("generator")
+            self.bucket_on_side(bucket_ready, "generator")
         dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
         dmem = b.get("dmem", (Bn * Te, d), self.dt)
         for l in reversed(range(L)):
@@ -467,8 +478,7 @@ class DecoderEngine(_StackBase):
             self.flush_dw()               # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None:      # this layer's (and, for the top layer, the final norm's) gradients are complete
                 self.flush_ln_grads(b)
-                self.join_side()
-                bucket_ready("dec_layer", l)
+                self.bucket_on_side(bucket_ready, "dec_layer", l)
         self.flush_ln_grads(b)
         self.join_side()
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
