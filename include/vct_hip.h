@@ -190,6 +190,17 @@ int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, int64_t ldl
                  int64_t ld_dl, float* row_ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batch assembly from a DEVICE-RESIDENT feature store (a split's clips packed into store [rows, E] fp32, clip i =
+ * rows offsets[i] .. offsets[i+1]): out[b, t, :] = store[offsets[idx[b]] + t] for t < len(clip idx[b]), else 0;
+ * mask[b, t] = 1 where padded.  out: [B, Tmax, E] of out_dtype (fp32, or bf16 = the encoder's compute type, which
+ * saves its input cast), mask: uint8/bool [B, Tmax].  E % 4 == 0 takes the 16-byte path.
+ * replaces: per-sample np.load + torch.tensor (dataloader.py:378-386), zero-pad + mask build on the host
+ * (_make_mask_video, dataloader.py:233-247) and the per-step H2D copies (train.py:120-121).
+ * --------------------------------------------------------------------------------------------- */
+int vct_gather_pad_rows(int out_dtype, int B, int Tmax, int E, const float* store, const int64_t* offsets,
+                        const int64_t* idx, void* out, uint8_t* mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused Adam / AdamW step over the flat fp32 parameter buffer + bf16 shadow refresh, one launch.
  * replaces: torch.optim.Adam(...).step() / AdamW when weight_decay != 0 (train.py:24-31,126); same
  * arithmetic as torch's single-tensor Adam (no amsgrad).  step_dev: DEVICE int32 counter of steps

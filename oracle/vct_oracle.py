@@ -598,3 +598,38 @@ def synthetic_batch(B, T, d_in, S, vocab, seed=0, ragged=False):
             ids[0, full] = lo
             ids[0, -1] = 102
     return feats, mask, ids
+
+
+# ---- input path and early stopping --------------------------------
+def load_clip(a: np.ndarray) -> np.ndarray:
+    """dataloader.py:378-386: fp32; a file stored [E, T] (shape[0] > shape[1]) is transposed to [T, E]."""
+    a = np.asarray(a, dtype=np.float32)
+    return a.T.copy() if a.shape[0] > a.shape[1] else a
+
+
+def make_mask_video(clips: Sequence[np.ndarray]):
+    """dataloader.py:233-247: zero-pad clips [T_i, E] to [B, max T, E]; mask True = padded frame."""
+    B, E, lens = len(clips), clips[0].shape[1], [c.shape[0] for c in clips]
+    feat = np.zeros((B, max(lens), E), np.float32)
+    mask = np.ones((B, max(lens)), bool)
+    for i, c in enumerate(clips):
+        feat[i, :lens[i]] = c
+        mask[i, :lens[i]] = False
+    return feat, mask
+
+
+def early_stopping_trace(losses: Sequence[float], patience: int, delta: float = 0.0):
+    """utils.py:36-59: the monitored value is negated once (`val_loss = -val_loss`) and everything after -- best
+    score, the stored `val_loss_min` -- uses the negated value; a call saves iff it sets a new best."""
+    counter, best, stop, vmin, saves, out = 0, None, False, float("inf"), 0, []
+    for v in losses:
+        s = -v
+        if best is None:
+            best, vmin, saves = s, s, saves + 1
+        elif s < best + delta:
+            counter += 1
+            stop = stop or counter >= patience
+        else:
+            best, vmin, saves, counter = s, s, saves + 1, 0
+        out.append({"counter": counter, "best_score": best, "early_stop": stop, "val_loss_min": vmin, "saves": saves})
+    return out

@@ -319,6 +319,32 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batch assembly from a device-resident feature store: one wave per output row (b, t).  Row t of clip idx[b] is
+// copied (and cast) when t < len(clip), zero-filled otherwise; lane 0 writes the padding-mask byte.
+template <typename TD>
+__global__ __launch_bounds__(256) void gather_pad_rows_kernel(const float* __restrict__ store, const int64_t* __restrict__ offsets,
+                                                              const int64_t* __restrict__ idx, int B, int Tmax, int E,
+                                                              TD* __restrict__ out, uint8_t* __restrict__ mask) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * Tmax) return;
+  const int b = row / Tmax, t = row % Tmax;
+  const int64_t clip = idx[b], r0 = offsets[clip], len = offsets[clip + 1] - r0;
+  const bool valid = t < len;
+  if (lane == 0) mask[row] = valid ? 0 : 1;
+  const float* src = store + (size_t)(r0 + (valid ? t : 0)) * E;
+  TD* dst = out + (size_t)row * E;
+  const int e4 = (E % 4 == 0) ? E / 4 : 0;     // rows are 16-byte aligned only then
+  for (int i = lane; i < e4; i += 64) {
+    PackT<float, 4> v = reinterpret_cast<const PackT<float, 4>*>(src)[i];    // unconditional load, zeroed after
+    PackT<TD, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o.v[j] = from_f<TD>(valid ? v.v[j] : 0.0f);
+    reinterpret_cast<PackT<TD, 4>*>(dst)[i] = o;
+  }
+  for (int i = e4 * 4 + lane; i < E; i += 64) dst[i] = from_f<TD>(valid ? src[i] : 0.0f);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __restrict__ x, int64_t ldx,
                                                           int64_t* __restrict__ out, int64_t out_stride) {
@@ -485,6 +511,21 @@ extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int
   return VCT_OK;
 }
 
+extern "C" int vct_gather_pad_rows(int out_dtype, int B, int Tmax, int E, const float* store, const int64_t* offsets,
+                                   const int64_t* idx, void* out, uint8_t* mask, void* stream) {
+  if (!dt_ok(out_dtype) || !store || !offsets || !idx || !out || !mask) return VCT_E_ARG;
+  if (B <= 0 || Tmax <= 0 || E <= 0) return VCT_E_SHAPE;
+  if ((E % 4 == 0) && ((((uintptr_t)store) & 15) || (((uintptr_t)out) & 15))) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (B * Tmax + 3) / 4;
+  if (out_dtype == VCT_BF16)
+    hipLaunchKernelGGL((gather_pad_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (bf16_t*)out, mask);
+  else
+    hipLaunchKernelGGL((gather_pad_rows_kernel<float>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (float*)out, mask);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
 extern "C" int vct_advance_seed(uint32_t* seed, void* stream) {
   if (!seed) return VCT_E_ARG;
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
@@ -494,7 +535,7 @@ extern "C" int vct_advance_seed(uint32_t* seed, void* stream) {
 
 extern "C" int vct_abi_version(void) { return VCT_ABI_VERSION; }
 extern "C" int vct_build_info(char* buf, int buflen) {
-  static const char info[] = "libvct_hip gfx950 (CDNA4) abi 1; bf16 mfma 16x16x32 + f32 mfma 16x16x4";
+  static const char info[] = "libvct_hip gfx950 (CDNA4) abi 2; bf16 mfma 16x16x32 + f32 mfma 16x16x4";
   int n = (int)sizeof(info) - 1;
   if (buf && buflen > 0) {
     int c = n < buflen - 1 ? n : buflen - 1;

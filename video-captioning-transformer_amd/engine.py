@@ -336,11 +336,9 @@ class EncoderEngine(_StackBase):
         b = self.buf((B, T))
         self.cur, self.shape = b, (B, T)
         Te, M = T + 1, B * (T + 1)
-        x_in = feats.reshape(B * T, Ein)
-        if self.dt != torch.float32:
-            x_in = ops.cast(x_in.contiguous(), b.get("feats_c", (B * T, Ein), self.dt))
-        else:
-            x_in = x_in.contiguous()
+        x_in = feats.reshape(B * T, Ein).contiguous()
+        if x_in.dtype != self.dt:        # fp32 features (reference contract); a DeviceLoader batch may already be bf16
+            x_in = ops.cast(x_in, b.get("feats_c", (B * T, Ein), self.dt))
         b.t["x_in"] = x_in
         u = b.get("u", (B * T, d), self.dt)
         ops.gemm(x_in, self.W("unify.0.weight"), u, bias=self.F("unify.0.bias"))

@@ -265,3 +265,13 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, w
 def adam_bump(step_dev):
     L.check(L.load().vct_adam_step(step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), 0, 0,
                                    0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, L.stream_ptr()), "vct_adam_step(bump)")
+
+
+def gather_pad_rows(store: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, tmax: int, out_dtype=torch.float32):
+    """store fp32 [rows, E] (packed clips), offsets int64 [n+1], idx int64 [B] -> (feat [B, tmax, E], mask bool [B, tmax])."""
+    B, E = idx.numel(), store.shape[1]
+    out = torch.empty(B, tmax, E, dtype=out_dtype, device=store.device)
+    mask = torch.empty(B, tmax, dtype=torch.bool, device=store.device)
+    L.check(L.load().vct_gather_pad_rows(L.dtype_code(out_dtype), B, tmax, E, store.data_ptr(), offsets.data_ptr(), idx.data_ptr(),
+                                         out.data_ptr(), mask.data_ptr(), L.stream_ptr()), "vct_gather_pad_rows")
+    return out, mask

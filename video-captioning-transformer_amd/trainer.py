@@ -120,6 +120,28 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         pass   # the backward schedule overwrites every gradient
 
+    # ---- checkpointing (checkpoint.save_training_state): moments and step live outside torch's per-param state ----
+    def state_dict(self):
+        sd = super().state_dict()
+        ps = self.model._ps
+        sd["vct_fused_adam"] = {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                                "step": int(self.step_dev.item()), "numel": ps.flat.numel(),
+                                "layout": [(k, int(ps.offsets[k])) for k in ps.params]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        fused = sd.pop("vct_fused_adam", None)
+        if fused is None:
+            raise ValueError("not a FusedAdam state (no 'vct_fused_adam' entry)")
+        ps = self.model._ps
+        if fused["numel"] != ps.flat.numel() or [tuple(x) for x in fused["layout"]] != [(k, int(ps.offsets[k])) for k in ps.params]:
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        super().load_state_dict(sd)
+        self.exp_avg.copy_(fused["exp_avg"])
+        self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+        self.step_dev.fill_(fused["step"])
+
 
 def build_optimizer(train_cfg: dict, model):
     """Optimizer + scheduler factory with the reference's config surface (train.py:20-49).  The
