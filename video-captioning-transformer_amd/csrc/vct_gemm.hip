@@ -374,8 +374,13 @@ int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn
 using namespace vct;
 
 // workspace layout: [split x M x N partials][split x M bias partials]
+// Single-pass (in-kernel) split-K reduce: the partials travel as write-through agent-scope stores, which are slow in
+// bulk.  Measured on MI355X: a layer's weight gradients (<= 12 MB of partials) gain ~6 us per GEMM from dropping the
+// second launch, the vocabulary dX (6 x 4864 x 512 fp32 = 60 MB of partials) LOSES 60 us -- so only small partial sets.
 static bool use_counters(const vct_gemm_desc* d, const Plan& pl) {
-  return d->tile_counters != nullptr && d->dtype == VCT_BF16 && (long)pl.tiles_m * pl.tiles_n <= (long)d->n_tile_counters;
+  const int64_t partial_bytes = (int64_t)pl.split * d->M * d->N * 4;
+  return d->tile_counters != nullptr && d->dtype == VCT_BF16 && (long)pl.tiles_m * pl.tiles_n <= (long)d->n_tile_counters &&
+         partial_bytes <= ((int64_t)16 << 20);
 }
 static int64_t ws_bytes(const vct_gemm_desc* d, const Plan& pl) {
   if (pl.split <= 1) return 0;
@@ -497,6 +502,7 @@ static Plan grouped_plan(const vct_gemm_desc* d, const GroupTile& t, long gt) {
   int split = gt >= 192 ? 1 : (int)((255 + gt) / gt);
   if (d->split_k >= 1) split = d->split_k;
   if (split > pl.nkt / 4) split = pl.nkt / 4 > 0 ? pl.nkt / 4 : 1;
+  while (split > 1 && (int64_t)split * d->M * d->N * 4 > ((int64_t)16 << 20)) split--;   // in-kernel reduce: small partial sets only
   if (split < 1) split = 1;
   pl.kt_per = (pl.nkt + split - 1) / split;
   pl.split = (pl.nkt + pl.kt_per - 1) / pl.kt_per;
