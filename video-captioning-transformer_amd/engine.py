@@ -117,6 +117,7 @@ class _StackBase:
         self._ws = None
         self._ln_pending = []
         self._dw_pending = []
+        self._kv_prefetched = None
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
     def W(self, k): return self.ps.c[self.pre + k]
@@ -139,6 +140,7 @@ class _StackBase:
     # overlap the next layer's dX chain.  The two big ones (generator) go out immediately, alone.
     overlap_dw = True
     group_dw = True
+    overlap_kv = True      # cross-attention K/V projections and d(memory) accumulation off the critical path
     _side = None
     _side_ws = None
 
@@ -208,15 +210,37 @@ class _StackBase:
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
             q = b.get(tag + "q", (Mq, d), self.dt)
-            kv = b.get(tag + "kv", (Mk, 2 * d), self.dt)
             ops.gemm(x, self.W(lp + "in_proj_weight")[:d], q, bias=self.F(lp + "in_proj_bias")[:d])
-            ops.gemm(kv_src, self.W(lp + "in_proj_weight")[d:], kv, bias=self.F(lp + "in_proj_bias")[d:])
+            kv = self._cross_kv(b, tag, lp, kv_src)
             k, v = kv[:, :d], kv[:, d:]
         o = b.get(tag + "o", (Mq, d), self.dt)
         ops.attn_fwd(q, k, v, o, Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=self.drop(site))
         a = b.get(tag + "a", (Mq, d), self.dt)
         ops.gemm(o, self.W(lp + "out_proj.weight"), a, bias=self.F(lp + "out_proj.bias"))
         return a
+
+    def _cross_kv(self, b, tag, lp, mem):
+        """K/V projection of the encoder memory for one cross-attention block.  It depends on the memory only, so
+        prefetch_cross_kv() issues it for every layer on the side stream at the start of the decoder stack, off the
+        critical path; here it is either picked up (after joining that stream) or computed in place."""
+        d = self.cfg["d"]
+        kv = b.get(tag + "kv", (mem.shape[0], 2 * d), self.dt)
+        if self._kv_prefetched:
+            if self._kv_prefetched == "pending":
+                self.join_side()
+                self._kv_prefetched = "joined"
+        else:
+            ops.gemm(mem, self.W(lp + "in_proj_weight")[d:], kv, bias=self.F(lp + "in_proj_bias")[d:])
+        return kv
+
+    def prefetch_cross_kv(self, b, mem, tags_lps):
+        if not self.overlap_kv:
+            return
+        d = self.cfg["d"]
+        for tag, lp in tags_lps:
+            kv = b.get(tag + "kv", (mem.shape[0], 2 * d), self.dt)
+            self._on_side(lambda ws, kv=kv, lp=lp: ops.gemm(mem, self.W(lp + "in_proj_weight")[d:], kv, bias=self.F(lp + "in_proj_bias")[d:]))
+        self._kv_prefetched = "pending"
 
     def _attn_block_bwd(self, b, tag, lp, da, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn, ds_res,
                         dkv_out=None, dkv_accumulate=False):
@@ -244,8 +268,10 @@ class _StackBase:
                          key_pad=key_pad, dropout=self.drop(site))
             ops.gemm(dq, self.W(lp + "in_proj_weight")[:d], dx, ta=False, tb=False, addend=ds_res)
             self.dw_gemm(dq, x, self.G(lp + "in_proj_weight")[:d], bias_grad=self.G(lp + "in_proj_bias")[:d])
-            ops.gemm(dkv, self.W(lp + "in_proj_weight")[d:], dkv_out, ta=False, tb=False,
-                     addend=dkv_out if dkv_accumulate else None)
+            # d(memory) is only read by the encoder backward: accumulate it on the side stream (in layer order)
+            run = self._on_side if self.overlap_kv else (lambda fn: fn(None))
+            run(lambda ws: ops.gemm(dkv, self.W(lp + "in_proj_weight")[d:], dkv_out, ta=False, tb=False,
+                                    addend=dkv_out if dkv_accumulate else None))
             self.dw_gemm(dkv, kv_src, self.G(lp + "in_proj_weight")[d:],
                          bias_grad=self.G(lp + "in_proj_bias")[d:])
         return dx
@@ -399,6 +425,7 @@ class DecoderEngine(_StackBase):
         """Embedding + decoder layers + final LayerNorm over the first Sd tokens of each ids row."""
         d, L = self.cfg["d"], self.cfg["layers"]
         M = Bn * Sd
+        self.prefetch_cross_kv(b, mem, [(f"L{l}.ca.", f"decoder.layers.{l}.multihead_attn.") for l in range(L)])
         x = ops.embed_fwd(ids, Sd, self.F("tgt_to_emb.weight"), self.pos, b.get("x0", (M, d), self.dt), dropout=self.drop(EMB_SITE))
         for l in range(L):
             lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
@@ -409,6 +436,7 @@ class DecoderEngine(_StackBase):
             x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, site + 4)
             f = self._ffn_fwd(b, tag + "ff.", lp, x2, site + 5)
             x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, site + 6)
+        self._kv_prefetched = None
         b.t["x_last"] = x
         return self._ln_fwd(b, "nf.", "decoder.norm.", x, None, None)
 
