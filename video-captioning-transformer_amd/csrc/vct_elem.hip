@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
                                                         float p_drop) {
   constexpr int VEC = EV<T>::VEC;
   using P = PackT<T, VEC>;
-  __shared__ int s_cnt;
-  __shared__ int s_wcnt[4];
+  __shared__ int s_wcnt[16];
   __shared__ int s_list[1024];
   __shared__ float s_part[256 * VEC];                  // [slot][d] partial sums
   const int n = blockIdx.x;
@@ -138,30 +137,59 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
     if (active && slot == 0) add_row(n);
   } else {
     int seen = 0;                                       // occurrences consumed so far (global order index)
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     for (int base = n; base < N && seen < occurrences; base += 1024) {
-      __syncthreads();
-      if (threadIdx.x == 0) s_cnt = 0;
-      __syncthreads();
-      for (int sub = 0; sub < 1024; sub += 256) {       // ordered compaction: ballot per wave, prefix over waves
-        const int j = base + sub + threadIdx.x;
-        const bool match = (j < N) && (ids[(size_t)(j / S) * id_bstride + (j % S)] == id);
-        const unsigned long long bal = __ballot(match);
-        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        if (l == 0) s_wcnt[w] = __popcll(bal);
-        __syncthreads();
-        int off = s_cnt;
-        for (int ww = 0; ww < w; ww++) off += s_wcnt[ww];
-        if (match) s_list[off + __popcll(bal & ((1ull << l) - 1ull))] = j;
-        __syncthreads();
-        if (threadIdx.x == 0) s_cnt += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        __syncthreads();
+      // ordered compaction of the matches among positions [base, base + 1024): the four id loads of a thread are
+      // issued together, one ballot per wave and 256-position slice, ONE barrier, prefix over (slice, wave)
+      bool match[4];
+      unsigned long long bal[4];
+#pragma unroll
+      for (int sub = 0; sub < 4; sub++) {
+        const int j = min(base + sub * 256 + (int)threadIdx.x, N - 1);
+        match[sub] = ids[(size_t)(j / S) * id_bstride + (j % S)] == id;
       }
-      const int found = s_cnt;
+      __syncthreads();                                  // the previous round's readers of s_list / s_wcnt are done
+#pragma unroll
+      for (int sub = 0; sub < 4; sub++) {
+        match[sub] = match[sub] && (base + sub * 256 + (int)threadIdx.x < N);
+        bal[sub] = __ballot(match[sub]);
+        if (l == 0) s_wcnt[sub * 4 + w] = __popcll(bal[sub]);
+      }
+      __syncthreads();
+      int total = 0;
+#pragma unroll
+      for (int sub = 0; sub < 4; sub++) {
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) {
+          if (ww == w && match[sub]) s_list[total + __popcll(bal[sub] & ((1ull << l) - 1ull))] = base + sub * 256 + threadIdx.x;
+          total += s_wcnt[sub * 4 + ww];
+        }
+      }
+      __syncthreads();
+      const int found = total;
       if (active) {
         // slot s takes list entries whose GLOBAL order index is congruent to s (mod slots)
-        int q = ((slot - seen) % slots + slots) % slots;
-        for (; q + slots < found; q += 2 * slots) { add_row(s_list[q]); add_row(s_list[q + slots]); }
-        if (q < found) add_row(s_list[q]);
+        // Eight rows are fetched before the first one is added (the loads are independent, the ADDS keep their order):
+        // a token that occurs in every caption ([CLS]) is otherwise a chain of ~N/(1024/slots) dependent L2 round trips.
+        constexpr int DEPTH = 8;
+        for (int q = ((slot - seen) % slots + slots) % slots; q < found; q += DEPTH * slots) {
+          P v[DEPTH];
+          int pos[DEPTH];
+#pragma unroll
+          for (int u = 0; u < DEPTH; u++) {
+            const int qi = q + u * slots;
+            pos[u] = qi < found ? s_list[qi] : -1;
+            v[u] = *reinterpret_cast<const P*>(dx + (size_t)(pos[u] >= 0 ? pos[u] : n) * d + chunk * VEC);
+          }
+#pragma unroll
+          for (int u = 0; u < DEPTH; u++) {
+            if (pos[u] >= 0) {
+#pragma unroll
+              for (int j = 0; j < VEC; j++)
+                acc[j] += to_f<T>(v[u].v[j]) * drop_mult(dr, (uint32_t)pos[u] * (uint32_t)d + (uint32_t)(chunk * VEC + j));
+            }
+          }
+        }
       }
       seen += found;
     }
