@@ -32,7 +32,7 @@ def smoke():
         f, mk, i = (torch.from_numpy(a).to(dev) for a in (feats, mask, ids))
         loss = m([f], [mk], i)
         loss.backward()
-        assert abs(float(loss) - ref_loss) < tol * abs(ref_loss), (float(loss), ref_loss)
+        assert abs(float(loss.detach()) - ref_loss) < tol * abs(ref_loss), (float(loss.detach()), ref_loss)
         for k, g in ref_grads.items():
             mine = m._ps.g[k].double().cpu().numpy()
             err = np.linalg.norm(mine - g) / max(np.linalg.norm(g), 1e-30)
