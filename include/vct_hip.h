@@ -222,6 +222,14 @@ int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n
  * (out_stride lets the decode loop write straight into column t of the id matrix ys[B, max_len]) */
 int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
                     void* stream);
+/* one greedy-decode selection step: vct_argmax_rows into column t of the id matrix PLUS the loop's end bookkeeping
+ * (MMT4Caption.py:166-171) on the device: ended[row] (uint8, sticky) is set when the row emits end_id; ended_count
+ * counts such rows; the row that completes the set stores t into all_ended_at[0] (atomic min).  Integer atomics
+ * only.  The host reads all_ended_at every few steps instead of syncing per token (`.tolist()`, MMT4Caption.py:168).
+ * Before a decode: ended = 0, ended_count = 0, all_ended_at = max_len. */
+int vct_greedy_select(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
+                      int64_t end_id, uint8_t* ended, int32_t* ended_count, int64_t* all_ended_at, int32_t t,
+                      void* stream);
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);
 

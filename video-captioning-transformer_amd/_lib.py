@@ -56,6 +56,7 @@ _SIGS = {
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),
+    "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp]),
 }

@@ -375,7 +375,10 @@ __global__ __launch_bounds__(256) void gather_pad_rows_kernel(const float* __res
 
 template <typename T>
 __global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __restrict__ x, int64_t ldx,
-                                                          int64_t* __restrict__ out, int64_t out_stride) {
+                                                          int64_t* __restrict__ out, int64_t out_stride,
+                                                          int64_t end_id, uint8_t* __restrict__ ended,
+                                                          int32_t* __restrict__ ended_count,
+                                                          unsigned long long* __restrict__ all_ended_at, int t) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   const T* r = x + (size_t)blockIdx.x * ldx;
@@ -396,7 +399,14 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(int cols, const T* __r
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; w++)
       if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
-    out[(size_t)blockIdx.x * out_stride] = (bi == 0x7fffffff) ? 0 : bi;
+    const int tok = (bi == 0x7fffffff) ? 0 : bi;
+    out[(size_t)blockIdx.x * out_stride] = tok;
+    // greedy-decode bookkeeping (MMT4Caption.py:166-171): sticky per-row end flag; the row that completes the set
+    // records the step.  Integer atomics only: the result does not depend on arrival order.
+    if (ended != nullptr && tok == end_id && !ended[blockIdx.x]) {
+      ended[blockIdx.x] = 1;
+      if (atomicAdd(ended_count, 1) + 1 == (int)gridDim.x) atomicMin(all_ended_at, (unsigned long long)t);
+    }
   }
 }
 
@@ -532,9 +542,28 @@ extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int
   if (rows <= 0 || cols <= 0 || out_stride <= 0) return VCT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride);
+    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
+                       (int64_t)0, (uint8_t*)nullptr, (int32_t*)nullptr, (unsigned long long*)nullptr, 0);
   else
-    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride);
+    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
+                       (int64_t)0, (uint8_t*)nullptr, (int32_t*)nullptr, (unsigned long long*)nullptr, 0);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+extern "C" int vct_greedy_select(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
+                                 int64_t end_id, uint8_t* ended, int32_t* ended_count, int64_t* all_ended_at, int32_t t,
+                                 void* stream) {
+  if (!dt_ok(dtype) || !x || !out || !ended || !ended_count || !all_ended_at) return VCT_E_ARG;
+  if (rows <= 0 || cols <= 0 || out_stride <= 0 || t < 0) return VCT_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* at = reinterpret_cast<unsigned long long*>(all_ended_at);
+  if (dtype == VCT_BF16)
+    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
+                       end_id, ended, ended_count, at, (int)t);
+  else
+    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
+                       end_id, ended, ended_count, at, (int)t);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -514,8 +514,8 @@ class DecoderEngine(_StackBase):
 
 
 class DecodeState:
-    """Static buffers of one greedy-decode session (B, Te, Lmax): id matrix, per-layer self-attention KV
-    cache [B, Lmax, 2d], per-layer cross-attention K/V of the memory (computed once), step temporaries
+    """Static buffers of one greedy-decode session (B, Te, Lmax): id matrix, per-layer self-attention
+    cache [B, Lmax, 3d] (packed q | k | v of every consumed token), per-layer cross-attention K/V of the memory (computed once), step temporaries
     and the hipGraphs of the per-token step (one per position; every kernel argument is baked)."""
 
     def __init__(self, eng: "DecoderEngine", Bn: int, Te: int, Lmax: int):
@@ -523,8 +523,9 @@ class DecodeState:
         self.B, self.Te, self.Lmax = Bn, Te, Lmax
         self.ys = torch.zeros(Bn, Lmax, dtype=torch.long, device=dev)
         self.ended = torch.zeros(Bn, dtype=torch.bool, device=dev)
+        self.ended_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.all_ended_at = torch.full((1,), Lmax, dtype=torch.long, device=dev)   # first t at which every row had ended
-        self.kv_self = [torch.zeros(Bn * Lmax, 2 * d, dtype=dt, device=dev) for _ in range(L)]
+        self.kv_self = [torch.zeros(Bn * Lmax, 3 * d, dtype=dt, device=dev) for _ in range(L)]    # [q | k | v] per slot
         self.kv_cross = [torch.empty(Bn * Te, 2 * d, dtype=dt, device=dev) for _ in range(L)]
         self.b = _Buf(dev)
         self.graphs = {}
@@ -536,6 +537,7 @@ def _decoder_decode_begin(self, st: DecodeState, mem: torch.Tensor, start_id: in
     st.ys.fill_(pad_id)
     st.ys[:, 0] = start_id
     st.ended.zero_()
+    st.ended_count.zero_()
     st.all_ended_at.fill_(st.Lmax)
     for l in range(self.cfg["layers"]):
         lp = f"decoder.layers.{l}.multihead_attn."
@@ -554,12 +556,13 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
     for l in range(L):
         lp, tag = f"decoder.layers.{l}.", f"L{l}."
         sa = lp + "self_attn."
-        q = b.get(tag + "q", (Bn, d), self.dt)
-        ops.gemm(x, self.W(sa + "in_proj_weight")[:d], q, bias=self.F(sa + "in_proj_bias")[:d])
-        kv_new = st.kv_self[l].view(Bn, Lmax, 2 * d)[:, t - 1, :]          # [B, 2d] view, row stride Lmax*2d
-        ops.gemm(x, self.W(sa + "in_proj_weight")[d:], kv_new, bias=self.F(sa + "in_proj_bias")[d:])
+        # ONE packed projection per token: q, k, v land in slot t-1 of the cache [B, Lmax, 3d] (k, v stay there for the
+        # later steps; q is read once, through the same row stride)
+        cache = st.kv_self[l]
+        qkv_new = cache.view(Bn, Lmax, 3 * d)[:, t - 1, :]                  # [B, 3d] view, row stride Lmax*3d
+        ops.gemm(x, self.W(sa + "in_proj_weight"), qkv_new, bias=self.F(sa + "in_proj_bias"))
         o = b.get(tag + "o", (Bn, d), self.dt)
-        ops.attn_fwd(q, st.kv_self[l][:, :d], st.kv_self[l][:, d:], o, Bn, H, 1, t, kv_batch_stride=Lmax * 2 * d)
+        ops.attn_fwd(qkv_new[:, :d], cache[:, d:2 * d], cache[:, 2 * d:], o, Bn, H, 1, t, kv_batch_stride=Lmax * 3 * d)
         a = b.get(tag + "a", (Bn, d), self.dt)
         ops.gemm(o, self.W(sa + "out_proj.weight"), a, bias=self.F(sa + "out_proj.bias"))
         x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, None)
@@ -579,11 +582,8 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
     y = self._ln_fwd(b, "nf.", "decoder.norm.", x, None, None)
     logits = b.get("logits", (Bn, self.Vp), self.dt)
     ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
-    ops.argmax_rows(logits, st.ys[:, t], cols=self.V)
-    # sticky end flags + the first step at which every row has ended (device side, no host sync)
-    st.ended |= st.ys[:, t] == end_id
-    done = st.ended.all()
-    st.all_ended_at.copy_(torch.where(done & (st.all_ended_at == Lmax), torch.full_like(st.all_ended_at, t), st.all_ended_at))
+    # arg-max into column t + sticky end flags + the first step at which every row has ended: one launch, no host sync
+    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
 DecoderEngine.decode_begin = _decoder_decode_begin

@@ -267,6 +267,14 @@ def adam_bump(step_dev):
                                    0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, L.stream_ptr()), "vct_adam_step(bump)")
 
 
+def greedy_select(x, out, end_id: int, ended, ended_count, all_ended_at, t: int, cols=None):
+    """argmax_rows into `out` (column t of the id matrix) + the decode loop's end-of-sequence bookkeeping, one launch."""
+    L.check(L.load().vct_greedy_select(L.dtype_code(x.dtype), x.shape[0], cols or x.shape[1], x.data_ptr(), _ld(x),
+                                       out.data_ptr(), out.stride(0), int(end_id), ended.data_ptr(), ended_count.data_ptr(),
+                                       all_ended_at.data_ptr(), int(t), L.stream_ptr()), "vct_greedy_select")
+    return out
+
+
 def gather_pad_rows(store: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, tmax: int, out_dtype=torch.float32):
     """store fp32 [rows, E] (packed clips), offsets int64 [n+1], idx int64 [B] -> (feat [B, tmax, E], mask bool [B, tmax])."""
     B, E = idx.numel(), store.shape[1]
