@@ -299,6 +299,14 @@ static bool gemm_can_split(const vct_gemm_desc* d) {
 }
 
 // overrides for experiments: desc.reserved = tile + 10 * nbuf; tile 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64 (0 auto); nbuf 1..3 (0 default)
+// Single-pass (in-kernel) split-K reduce: the partials travel as write-through agent-scope stores, which are slow in
+// bulk.  Measured on MI355X: a layer's weight gradients (<= 12 MB of partials) gain ~6 us per GEMM from dropping the
+// second launch, the vocabulary dX (6 x 4864 x 512 fp32 = 60 MB of partials) LOSES 60 us -- so only small partial sets.
+static bool use_counters(const vct_gemm_desc* d, const Plan& pl) {
+  const int64_t partial_bytes = (int64_t)pl.split * d->M * d->N * 4;
+  return d->tile_counters != nullptr && d->dtype == VCT_BF16 && (long)pl.tiles_m * pl.tiles_n <= (long)d->n_tile_counters &&
+         partial_bytes <= ((int64_t)16 << 20);
+}
 static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   Plan pl;
   pl.nbuf = 2;
@@ -338,11 +346,18 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   int split = 1;
   if (d->split_k > 1) split = d->split_k;
   else if (d->split_k == 0 && nt < 384 && pl.nkt >= 8) split = (int)((767 + nt) / nt);
-  if (!gemm_can_split(d) || !have_ws) split = 1;
+  // a GEMM with an epilogue (bias, activation, dropout, addend, derivative) can only split when the reduction happens
+  // inside the kernel, where the last workgroup of a tile applies the epilogue to the summed partials
+  const bool epilogue = !gemm_can_split(d);
+  if (!have_ws || (epilogue && (d->tile_counters == nullptr || !bf))) split = 1;
+  // measured (tools/bench_decode.py): splitting the reduction of an epilogue GEMM pays for GEMV-like shapes (decode at
+  // batch 1: 217 -> 198 us/token) and costs at batch 128 (241 -> 283 us/step: the write-through partials again)
+  if (epilogue && d->split_k == 0 && d->M > 16) split = 1;
   if (split > pl.nkt / 2) split = pl.nkt / 2 > 0 ? pl.nkt / 2 : 1;
   if (split < 1) split = 1;
   pl.kt_per = (pl.nkt + split - 1) / split;
   pl.split = (pl.nkt + pl.kt_per - 1) / pl.kt_per;
+  if (epilogue && pl.split > 1 && !use_counters(d, pl)) { pl.split = 1; pl.kt_per = pl.nkt; }
   return pl;
 }
 
@@ -374,14 +389,6 @@ int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn
 using namespace vct;
 
 // workspace layout: [split x M x N partials][split x M bias partials]
-// Single-pass (in-kernel) split-K reduce: the partials travel as write-through agent-scope stores, which are slow in
-// bulk.  Measured on MI355X: a layer's weight gradients (<= 12 MB of partials) gain ~6 us per GEMM from dropping the
-// second launch, the vocabulary dX (6 x 4864 x 512 fp32 = 60 MB of partials) LOSES 60 us -- so only small partial sets.
-static bool use_counters(const vct_gemm_desc* d, const Plan& pl) {
-  const int64_t partial_bytes = (int64_t)pl.split * d->M * d->N * 4;
-  return d->tile_counters != nullptr && d->dtype == VCT_BF16 && (long)pl.tiles_m * pl.tiles_n <= (long)d->n_tile_counters &&
-         partial_bytes <= ((int64_t)16 << 20);
-}
 static int64_t ws_bytes(const vct_gemm_desc* d, const Plan& pl) {
   if (pl.split <= 1) return 0;
   return (int64_t)pl.split * ((int64_t)d->M * d->N + d->M) * 4;

@@ -284,7 +284,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   for (int c = 0; c < CPL; c++)
 #pragma unroll
     for (int q = 0; q < VO; q++) bvec[c][q] = 0.0f;
-  if (p.bias != nullptr && !part) {
+  if (p.bias != nullptr && (!part || p.counters != nullptr)) {   // split-K: the in-kernel reduce applies the epilogue
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       const int col = n0 + wn * WN + ((c * 64 + lane) % CPR) * VO;
@@ -293,6 +293,48 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
     }
   }
   struct alignas(16) OutV { TO e[VO]; };
+  // bias / activation (+ saved pre-activation) / activation derivative / dropout / residual-gradient accumulate on
+  // VO consecutive columns of one row, then the store -- shared by the direct path and the in-kernel split-K reduce
+  auto finish = [&](const int row, const int col, const float (&v)[VO], const float (&bv)[VO], const bool full) {
+    if (full) {
+      OutV dv, av, ov, pv;
+      const bool has_d = dact != nullptr, has_a = addend != nullptr;
+      if (has_d) dv = *reinterpret_cast<const OutV*>(dact + (size_t)row * p.ld_dact + col);
+      if (has_a) av = *reinterpret_cast<const OutV*>(addend + (size_t)row * p.ld_addend + col);
+#pragma unroll
+      for (int q = 0; q < VO; q++) {
+        float x = v[q] + bv[q];
+        pv.e[q] = from_f<TO>(x);
+        x = act_f(p.act, x);
+        if (has_d) x *= dact_f(p.dact_kind, to_f<TO>(dv.e[q]));
+        x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+        if (has_a) x += to_f<TO>(av.e[q]);
+        ov.e[q] = from_f<TO>(x);
+      }
+      if (nt_store) {
+        // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
+      } else {
+        *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
+      }
+      if (preact != nullptr) {
+        if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
+        else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
+      }
+    } else {
+      for (int q = 0; q < VO; q++) {
+        if (col + q >= p.N) break;
+        float x = v[q] + bv[q];
+        if (preact != nullptr) preact[(size_t)row * p.ld_preact + col + q] = from_f<TO>(x);
+        x = act_f(p.act, x);
+        if (dact != nullptr) x *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
+        x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
+        if (addend != nullptr) x += to_f<TO>(addend[(size_t)row * p.ld_addend + col + q]);
+        C[(size_t)row * p.ldc + col + q] = from_f<TO>(x);
+      }
+    }
+  };
   static_for<TM>([&](auto I) {
     constexpr int i = decltype(I)::value;
     static_for<TN>([&](auto J) {
@@ -330,44 +372,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         }
         return;
       }
-      if (full) {
-        OutV dv, av, ov, pv;
-        const bool has_d = dact != nullptr, has_a = addend != nullptr;
-        if (has_d) dv = *reinterpret_cast<const OutV*>(dact + (size_t)row * p.ld_dact + col);
-        if (has_a) av = *reinterpret_cast<const OutV*>(addend + (size_t)row * p.ld_addend + col);
-#pragma unroll
-        for (int q = 0; q < VO; q++) {
-          float x = v[q] + bvec[c][q];
-          pv.e[q] = from_f<TO>(x);
-          x = act_f(p.act, x);
-          if (has_d) x *= dact_f(p.dact_kind, to_f<TO>(dv.e[q]));
-          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
-          if (has_a) x += to_f<TO>(av.e[q]);
-          ov.e[q] = from_f<TO>(x);
-        }
-        if (nt_store) {
-          // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident
-          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
-        } else {
-          *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
-        }
-        if (preact != nullptr) {
-          if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
-          else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
-        }
-      } else {
-        for (int q = 0; q < VO; q++) {
-          if (col + q >= p.N) break;
-          float x = v[q] + bvec[c][q];
-          if (preact != nullptr) preact[(size_t)row * p.ld_preact + col + q] = from_f<TO>(x);
-          x = act_f(p.act, x);
-          if (dact != nullptr) x *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
-          x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
-          if (addend != nullptr) x += to_f<TO>(addend[(size_t)row * p.ld_addend + col + q]);
-          C[(size_t)row * p.ldc + col + q] = from_f<TO>(x);
-        }
-      }
+      finish(row, col, v, bvec[c], full);
     });
   });
 
@@ -405,18 +410,13 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
               s[q] += t0; s[q + 1] += t1;
             }
           }
-          OutV ov;
-#pragma unroll
-          for (int q = 0; q < VO; q++) ov.e[q] = from_f<TO>(s[q]);
-          *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
         } else {
           for (int q = 0; q < VO; q++) {
             if (col + q >= p.N) break;
-            float a = 0.0f;
-            for (int z = 0; z < p.split; z++) a += coherent_load1(src + (size_t)z * zstride + q);
-            C[(size_t)row * p.ldc + col + q] = from_f<TO>(a);
+            for (int z = 0; z < p.split; z++) s[q] += coherent_load1(src + (size_t)z * zstride + q);
           }
         }
+        finish(row, col, s, bvec[c], full);
       });
     });
     if (p.bias_grad != nullptr && tile_n == 0) {

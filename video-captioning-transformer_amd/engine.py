@@ -550,6 +550,7 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
     keys/values of positions < t-1 are the cached projections of the same inputs."""
     d, H, L, Bn, Te, Lmax = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax
     b = st.b
+    ws = self.gemm_ws()      # split-K over the reduction for these M = batch GEMMs (a few output tiles, long K), reduced in-kernel
     self.p_drop = 0.0
     pos_row = self.pos[t - 1:t]                       # positional row of the consumed token
     x = ops.embed_fwd(st.ys[:, t - 1:t], 1, self.F("tgt_to_emb.weight"), pos_row, b.get("x0", (Bn, d), self.dt))
@@ -560,28 +561,28 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
         # later steps; q is read once, through the same row stride)
         cache = st.kv_self[l]
         qkv_new = cache.view(Bn, Lmax, 3 * d)[:, t - 1, :]                  # [B, 3d] view, row stride Lmax*3d
-        ops.gemm(x, self.W(sa + "in_proj_weight"), qkv_new, bias=self.F(sa + "in_proj_bias"))
+        ops.gemm(x, self.W(sa + "in_proj_weight"), qkv_new, bias=self.F(sa + "in_proj_bias"), workspace=ws)
         o = b.get(tag + "o", (Bn, d), self.dt)
         ops.attn_fwd(qkv_new[:, :d], cache[:, d:2 * d], cache[:, 2 * d:], o, Bn, H, 1, t, kv_batch_stride=Lmax * 3 * d)
         a = b.get(tag + "a", (Bn, d), self.dt)
-        ops.gemm(o, self.W(sa + "out_proj.weight"), a, bias=self.F(sa + "out_proj.bias"))
+        ops.gemm(o, self.W(sa + "out_proj.weight"), a, bias=self.F(sa + "out_proj.bias"), workspace=ws)
         x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, None)
         ca = lp + "multihead_attn."
         qc = b.get(tag + "qc", (Bn, d), self.dt)
-        ops.gemm(x1, self.W(ca + "in_proj_weight")[:d], qc, bias=self.F(ca + "in_proj_bias")[:d])
+        ops.gemm(x1, self.W(ca + "in_proj_weight")[:d], qc, bias=self.F(ca + "in_proj_bias")[:d], workspace=ws)
         oc = b.get(tag + "oc", (Bn, d), self.dt)
         ops.attn_fwd(qc, st.kv_cross[l][:, :d], st.kv_cross[l][:, d:], oc, Bn, H, 1, Te)
         c = b.get(tag + "c", (Bn, d), self.dt)
-        ops.gemm(oc, self.W(ca + "out_proj.weight"), c, bias=self.F(ca + "out_proj.bias"))
+        ops.gemm(oc, self.W(ca + "out_proj.weight"), c, bias=self.F(ca + "out_proj.bias"), workspace=ws)
         x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, None)
         h = b.get(tag + "h", (Bn, self.cfg["ff"]), self.dt)
-        ops.gemm(x2, self.W(lp + "linear1.weight"), h, bias=self.F(lp + "linear1.bias"), act=self.cfg["activation"])
+        ops.gemm(x2, self.W(lp + "linear1.weight"), h, bias=self.F(lp + "linear1.bias"), act=self.cfg["activation"], workspace=ws)
         f = b.get(tag + "f", (Bn, d), self.dt)
-        ops.gemm(h, self.W(lp + "linear2.weight"), f, bias=self.F(lp + "linear2.bias"))
+        ops.gemm(h, self.W(lp + "linear2.weight"), f, bias=self.F(lp + "linear2.bias"), workspace=ws)
         x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, None)
     y = self._ln_fwd(b, "nf.", "decoder.norm.", x, None, None)
     logits = b.get("logits", (Bn, self.Vp), self.dt)
-    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
+    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=ws)
     # arg-max into column t + sticky end flags + the first step at which every row has ended: one launch, no host sync
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
