@@ -247,7 +247,6 @@ class _StackBase:
         """da: grad of out_proj output (dropout-masked).  Returns dx = grad wrt x (+ ds_res)."""
         d, H = self.cfg["d"], self.cfg["nhead"]
         Mq, Mk = x.shape[0], kv_src.shape[0]
-        ws = self.gemm_ws()
         o = b.t[tag + "o"]
         d_o = b.get(tag + "d_o", (Mq, d), self.dt)
         ops.gemm(da, self.W(lp + "out_proj.weight"), d_o, ta=False, tb=False)
@@ -324,7 +323,6 @@ class _StackBase:
         """df: grad wrt f (dropout-masked).  Returns grad wrt x (+ ds_res)."""
         M, d = x.shape
         ff = self.cfg["ff"]
-        ws = self.gemm_ws()
         dhpre = b.get(tag + "dhpre", (M, ff), self.dt)
         ops.gemm(df, self.W(lp + "linear2.weight"), dhpre, ta=False, tb=False, act=self.cfg["activation"],
                  dact_src=b.t[tag + "hpre"], dropout=self.drop(site))
