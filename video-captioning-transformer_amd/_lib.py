@@ -111,9 +111,17 @@ def _ensure_current():
         stamp = os.path.join(_PKG, "build", "stamp")
         fresh = os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == mod._digest()
         if not fresh and os.path.exists(mod._hipcc()):
+            import fcntl
             import sys
-            print("[vct_amd] libvct_hip.so is missing or older than csrc/: rebuilding with hipcc ...", file=sys.stderr)
-            mod.build_library()
+            os.makedirs(os.path.join(_PKG, "build"), exist_ok=True)
+            with open(os.path.join(_PKG, "build", "lock"), "w") as lk:     # one rank of a multi-process launch builds
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                try:
+                    if not (os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == mod._digest()):
+                        print("[vct_amd] libvct_hip.so is missing or older than csrc/: rebuilding with hipcc ...", file=sys.stderr)
+                        mod.build_library()
+                finally:
+                    fcntl.flock(lk, fcntl.LOCK_UN)
     except Exception as e:   # a failed rebuild surfaces below as "library missing" or as a load error
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"could not build libvct_hip.so: {e}")
