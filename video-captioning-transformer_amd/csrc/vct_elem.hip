@@ -230,10 +230,11 @@ __global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, in
                                                         const int64_t* __restrict__ labels, int64_t lbstride,
                                                         int64_t pad_id, float alpha, T* __restrict__ dlogits, int64_t ld_dl,
                                                         float* __restrict__ row_ws) {
-  __shared__ float red[16];
-  constexpr int VEC = EV<T>::VEC;
+  // one LDS array per block reduction: each costs ONE barrier (no guard barrier before reusing a shared scratch)
+  __shared__ float red_m[16], red_s[16], red_q[16], red_c[16];
+  constexpr int VEC = EV<T>::VEC, NW = NT / 64;
   using P = PackT<T, VEC>;
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const T* x = logits + (size_t)n * ldl;
   const int64_t y = labels[(size_t)(n / S) * lbstride + (n % S)];
   const bool valid = (y != pad_id);
@@ -259,13 +260,23 @@ __global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, in
 #pragma unroll
     for (int j = 0; j < VEC; j++) mx = fmaxf(mx, e[it][j]);
   }
-  mx = block_max<NT / 64>(mx, red);
+  mx = wave_max(mx);
+  if (ln == 0) red_m[wv] = mx;
+  __syncthreads();
+  mx = red_m[0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) mx = fmaxf(mx, red_m[i]);
   float se = 0.0f;
 #pragma unroll
   for (int it = 0; it < IT; it++)
 #pragma unroll
     for (int j = 0; j < VEC; j++) { e[it][j] = __expf(e[it][j] - mx); se += e[it][j]; }   // padding: exp(-inf) = 0
-  se = block_sum<NT / 64>(se, red);
+  se = wave_sum(se);
+  if (ln == 0) red_s[wv] = se;
+  __syncthreads();
+  se = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NW; i++) se += red_s[i];
   const float inv = 1.0f / se;
   const float beta = 1.0f - alpha;
   const float py = __expf(xy - mx) * inv;
@@ -282,8 +293,13 @@ __global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, in
         q += big ? pj : 0.0f;
         cnt += big ? 0.0f : 1.0f;
       }
-    q = block_sum<NT / 64>(q, red);
-    cnt = block_sum<NT / 64>(cnt, red);
+    q = wave_sum(q);
+    cnt = wave_sum(cnt);
+    if (ln == 0) { red_q[wv] = q; red_c[wv] = cnt; }
+    __syncthreads();
+    q = 0.0f; cnt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { q += red_q[i]; cnt += red_c[i]; }
     cnt -= (float)(IT * NT * VEC - V);                 // masked / padding slots were counted as "small"
     if (py >= 1e-7f) q -= py; else cnt -= 1.0f;        // remove the label column
   }
