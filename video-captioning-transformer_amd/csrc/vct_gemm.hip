@@ -409,6 +409,8 @@ static int check_desc(const vct_gemm_desc* d) {
   if (d->lda % vec || d->ldb % vec) return VCT_E_ALIGN;
   if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return VCT_E_ALIGN;
   if (d->dact_src != nullptr && d->act == VCT_ACT_NONE) return VCT_E_ARG;  // dact needs the activation kind
+  // bf16 path: the bias gradient is fused into the weight-gradient form only (dW = A^T B, fp32 out)
+  if (d->bias_grad != nullptr && d->dtype == VCT_BF16 && !(d->ta == 1 && d->tb == 0 && d->out_dtype == VCT_F32)) return VCT_E_ARG;
   return VCT_OK;
 }
 

@@ -189,25 +189,45 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
 #pragma unroll
     for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
   }
-  const bool do_bias_grad = (p.bias_grad != nullptr) && (tile_n == 0) && (wn == 0);
+  // the bias gradient only exists for the weight-gradient form (dW = dY^T X, fp32 out): everywhere else its accumulators
+  // and its branch are compiled out (16 VGPRs back, one basic block per K tile)
+  constexpr bool BG = (TA == 1 && TB == 0 && sizeof(TO) == 4);
+  const bool do_bias_grad = BG && (p.bias_grad != nullptr) && (tile_n == 0) && (wn == 0);
   const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
+  // One K tile (two 32-deep MFMA steps).  ALL fragment reads of the tile are issued before the first MFMA and the
+  // bias-gradient MFMAs sit behind one branch at the END: a branch between the two k-steps (the former shape of this
+  // loop) splits the basic block, and hipcc then issues "6 reads, wait for all, 8 MFMAs" twice per tile with the LDS
+  // latency of the second group fully exposed.  As one block the k-step-1 reads fly under the k-step-0 MFMAs.
   auto compute = [&](const unsigned char* la, const unsigned char* lb) {
+    constexpr int KS = BK2 / 32;
+    bf16x8 fa[KS][TM], fb[KS][TN];
 #pragma unroll
-    for (int ks = 0; ks < BK2 / 32; ks++) {
-      bf16x8 fa[TM], fb[TN];
+    for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) fa[i] = frag2<A_MC, BM, KSPLIT>(la, wm * WM + i * 16, ks, lane);
+      for (int i = 0; i < TM; i++) fa[ks][i] = frag2<A_MC, BM, KSPLIT>(la, wm * WM + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < TN; j++) fb[j] = frag2<B_MC, BN, KSPLIT>(lb, wn * WN + j * 16, ks, lane);
+      for (int j = 0; j < TN; j++) fb[ks][j] = frag2<B_MC, BN, KSPLIT>(lb, wn * WN + j * 16, ks, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    // schedule shape: every LDS fragment read of the tile first, then the MFMAs (the compiler inserts counted lgkmcnt
+    // waits, so the k-step-0 MFMAs start as soon as their six fragments are back while the k-step-1 reads are in flight);
+    // left alone hipcc minimises registers instead: 2-4 reads, wait for all, 2-4 MFMAs, five times per tile
+    constexpr int N_DSREAD = KS * (TM * (A_MC ? 2 : 1) + TN * (B_MC ? 2 : 1));
+    __builtin_amdgcn_sched_group_barrier(0x100, N_DSREAD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN, 0);
+    if constexpr (BG) {
       if (do_bias_grad) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], ones, accb[i], 0, 0, 0);
       }
     }
   };
@@ -433,8 +453,12 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   }
 }
 
+// waves per SIMD the register allocator must leave room for: the eight-wave tiles are sized so that 2 (128x128) or
+// 3 (128x64) workgroups share a CU -- one VGPR too many (130 instead of 128) silently halves that
+constexpr int gemm_min_waves(int bm, int bn, int nw) { return nw == 8 ? (bm * bn == 128 * 128 ? 4 : (bm * bn == 128 * 64 ? 6 : 1)) : 1; }
+
 template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM = 2, int WGN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, WGM * WGN)) void gemm_bf16_v2_kernel(const GemmP p) {
   gemm_bf16_v2_body<TO, TA, TB, BM, BN, NBUF, WGM, WGN>(p, blockIdx.x, blockIdx.z);
 }
 
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_kernel(const Gemm
 // workgroup looks its problem up in a by-value table; each problem's run of workgroups starts at a multiple of 8
 // so that `bid & 7` is still the XCD the hardware dispatches the workgroup to.
 template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_v2_grouped_kernel(const GemmGroupP g) {
+__global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, WGM * WGN)) void gemm_bf16_v2_grouped_kernel(const GemmGroupP g) {
   const int b = blockIdx.x;
   int gi = 0;
 #pragma unroll
