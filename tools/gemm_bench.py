@@ -11,6 +11,8 @@ from vct_amd import _lib as L  # noqa: E402
 
 DEV = "cuda"
 SHAPES = [  # name, ta, tb, M, N, K, out
+    ("square   NT 4096x4096x4096", 0, 1, 4096, 4096, 4096, torch.bfloat16),
+    ("square   TN 4096x4096x4096", 1, 0, 4096, 4096, 4096, torch.float32),
     ("gen_fwd  NT 4864x30522x512", 0, 1, 4864, 30522, 512, torch.bfloat16),
     ("gen_dx   NN 4864x512x30522", 0, 0, 4864, 512, 30522, torch.bfloat16),
     ("gen_dw   TN 30522x512x4864", 1, 0, 30522, 512, 4864, torch.float32),
