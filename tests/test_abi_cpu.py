@@ -59,6 +59,38 @@ def test_argument_errors_are_codes_not_crashes(lib_path):
         _lib.check(700, "x")
 
 
+def test_new_entry_points_validate_arguments(lib_path):
+    from vct_amd import _lib
+    lib = _lib.load()
+    assert lib.vct_gemm_grouped(None, 3, None) == -1
+    arr = (_lib.GemmDesc * 9)()
+    assert lib.vct_gemm_grouped(arr, 9, None) == -1                    # more than VCT_GEMM_GROUP_MAX problems
+    assert lib.vct_gemm_grouped(arr, 2, None) == -1                    # null operands inside the descriptors
+    assert lib.vct_gemm_grouped_workspace_bytes(arr, 2, 5) == 0
+    assert lib.vct_greedy_select(1, 4, 10, None, 16, None, 1, 102, None, None, None, 3, None) == -1
+    assert lib.vct_gather_pad_rows(0, 4, 3, 16, None, None, None, None, None, None) == -1
+
+
+def test_descriptor_structs_match_the_c_header(tmp_path):
+    """ctypes mirrors of the descriptor structs must have the C compiler's size and field offsets."""
+    from vct_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "vct_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vct_gemm_desc), offsetof(vct_gemm_desc, workspace), offsetof(vct_gemm_desc, tile_counters),
+         sizeof(vct_attn_desc), offsetof(vct_attn_desc, d_o), offsetof(vct_attn_desc, q_bs));
+  return 0;
+}''')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    G, A = _lib.GemmDesc, _lib.AttnDesc
+    assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset]
+
+
 def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):
     from vct_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
