@@ -102,13 +102,17 @@ int64_t vct_gemm_grouped_workspace_bytes(const vct_gemm_desc* descs, int32_t n, 
  * replaces: F.scaled_dot_product_attention + mask merge inside nn.MultiheadAttention
  * (torch nn/functional.py:6553-6570,6629) as used at MMEncoder.py:274, CapDecoder.py:49-52,70-75.
  *   q: rows b*Lq+i, cols h*hd..; k,v: rows b*Lk+j.  ld in elements.  causal: key j > query i masked.
- *   key_pad: uint8 [B,Lk], 1 = padded key (masked) or NULL.  Limits: Lq, Lk <= 64, hd <= 128.
+ *   key_pad: uint8 / bool [B, Lk - key_pad_shift], 1 = padded key (masked) or NULL; the first key_pad_shift keys are never
+ *   padded (the encoder passes the raw frame mask [B,T] with shift 1: key 0 is the aggregation token, MMEncoder.py:252-257).
+ *   key_ids: alternative to key_pad -- int64 token ids, key j of batch b is padded iff key_ids[b*key_ids_bs + j] == pad_id
+ *   (the decoder passes its id matrix: tgt_padding_mask[:, :-1] of CapDecoder.py:45-47 without materialising it).
+ *   Limits: Lq, Lk <= 64, hd <= 128.
  * --------------------------------------------------------------------------------------------- */
 typedef struct vct_attn_desc {
   int32_t dtype;
   int32_t B, H, Lq, Lk, hd;
   int32_t causal;
-  int32_t reserved;
+  int32_t key_pad_shift;
   const void* q; int64_t ldq;
   const void* k; int64_t ldk;
   const void* v; int64_t ldv;
@@ -123,6 +127,7 @@ typedef struct vct_attn_desc {
   /* optional batch strides in ELEMENTS (0 = dense: L * ld).  A KV cache [B, Lmax, ...] read with
    * Lk < Lmax sets k_bs = v_bs = Lmax * ld. */
   int64_t q_bs, k_bs, v_bs, o_bs;
+  const int64_t* key_ids; int64_t key_ids_bs; int64_t pad_id;
 } vct_attn_desc;
 int vct_attn_fwd(const vct_attn_desc* d, void* stream);
 int vct_attn_bwd(const vct_attn_desc* d, void* stream);

@@ -29,10 +29,11 @@ class GemmDesc(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [("dtype", i32), ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("hd", i32), ("causal", i32),
-                ("reserved", i32), ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64),
+                ("key_pad_shift", i32), ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64),
                 ("o", vp), ("ldo", i64), ("key_pad", vp), ("seed", vp), ("site", u32), ("p_drop", f32),
                 ("d_o", vp), ("ld_do", i64), ("dq", vp), ("ld_dq", i64), ("dk", vp), ("ld_dk", i64),
-                ("dv", vp), ("ld_dv", i64), ("q_bs", i64), ("k_bs", i64), ("v_bs", i64), ("o_bs", i64)]
+                ("dv", vp), ("ld_dv", i64), ("q_bs", i64), ("k_bs", i64), ("v_bs", i64), ("o_bs", i64),
+                ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64)]
 
 
 _SIGS = {

@@ -22,7 +22,8 @@ struct AttnP {
   const void* k; long ldk;
   const void* v; long ldv;
   void* o; long ldo;
-  const uint8_t* key_pad;
+  const uint8_t* key_pad; int key_pad_shift;
+  const int64_t* key_ids; long key_ids_bs; long pad_id;
   const uint32_t* seed; uint32_t site; float p_drop;
   const void* d_o; long ld_do;
   void* dq; long ld_dq;
@@ -144,10 +145,16 @@ __device__ __forceinline__ float red16_sum(float v) {
 __device__ __forceinline__ bool key_masked(const AttnP& p, unsigned long long padmask, int qq, int kk) {
   return kk >= p.Lk || (p.causal && kk > qq) || ((padmask >> kk) & 1ull);
 }
-__device__ __forceinline__ unsigned long long load_padmask(const uint8_t* kp_row, int Lk, int lane) {
-  if (kp_row == nullptr) return 0ull;
-  const uint8_t v = kp_row[min(lane, Lk - 1)];
-  return __ballot(lane < Lk && v != 0);
+__device__ __forceinline__ unsigned long long load_padmask(const AttnP& p, int b, int lane) {
+  if (p.key_ids != nullptr) {
+    const long id = p.key_ids[(long)b * p.key_ids_bs + min(lane, p.Lk - 1)];
+    return __ballot(lane < p.Lk && id == p.pad_id);
+  }
+  if (p.key_pad == nullptr) return 0ull;
+  const int w = p.Lk - p.key_pad_shift;                 // mask row width; keys below the shift are never padded
+  const int j = min(max(lane - p.key_pad_shift, 0), w - 1);
+  const uint8_t v = p.key_pad[(long)b * w + j];
+  return __ballot(lane >= p.key_pad_shift && lane < p.Lk && v != 0);
 }
 
 // S^T tiles for query tile qt:  st[t][r] = scale * Q[q = qt*16 + i] . K[key = t*16 + g*4 + r]   (masked -> -inf)
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
     stage_multi<T, DT, 3>(jobs, p.hd, lane);
   }
   __syncthreads();
-  const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
+  const unsigned long long kp_row = load_padmask(p, b, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   const float scale = 1.0f / sqrtf((float)p.hd);
   const int hd4 = (p.hd + 3) / 4;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
     stage_multi<T, DT, 4>(jobs, p.hd, lane);
   }
   __syncthreads();
-  const unsigned long long kp_row = load_padmask(p.key_pad ? p.key_pad + (long)b * p.Lk : nullptr, p.Lk, lane);
+  const unsigned long long kp_row = load_padmask(p, b, lane);
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   const float scale = 1.0f / sqrtf((float)p.hd);
   const int hd4 = (p.hd + 3) / 4;
@@ -509,7 +516,9 @@ static int attn_common(const vct_attn_desc* d, bool bwd, void* stream) {
   p.B = d->B; p.H = d->H; p.Lq = d->Lq; p.Lk = d->Lk; p.hd = d->hd; p.causal = d->causal;
   p.q = d->q; p.ldq = d->ldq; p.k = d->k; p.ldk = d->ldk; p.v = d->v; p.ldv = d->ldv;
   p.o = d->o; p.ldo = d->ldo;
-  p.key_pad = d->key_pad;
+  p.key_pad = d->key_pad; p.key_pad_shift = d->key_pad_shift;
+  p.key_ids = d->key_ids; p.key_ids_bs = d->key_ids_bs; p.pad_id = d->pad_id;
+  if (d->key_pad_shift < 0 || (d->key_pad != nullptr && d->key_pad_shift >= d->Lk)) return VCT_E_SHAPE;
   p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
   p.d_o = d->d_o; p.ld_do = d->ld_do;
   p.dq = d->dq; p.ld_dq = d->ld_dq; p.dk = d->dk; p.ld_dk = d->ld_dk; p.dv = d->dv; p.ld_dv = d->ld_dv;

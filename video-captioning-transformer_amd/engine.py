@@ -367,11 +367,12 @@ class EncoderEngine(_StackBase):
         u = b.get("u", (B * T, d), self.dt)
         ops.gemm(x_in, self.W("unify.0.weight"), u, bias=self.F("unify.0.bias"))
         x = ops.enc_frontend_fwd(u, self.pe_rows(T), b.get("x0", (M, d), self.dt), B, T)
+        # key-padding of the encoder's self-attention: the raw frame mask with a shift of one (key 0 = the aggregation
+        # token, never padded) -- read by the attention kernel directly, no [B, T+1] mask is built
         kpm = None
         if mask is not None:
-            kpm = b.get("kpm", (B, Te), torch.uint8)
-            kpm[:, 0] = 0
-            kpm[:, 1:] = mask
+            mk = mask if mask.is_contiguous() else mask.contiguous()
+            kpm = (mk.view(torch.uint8) if mk.dtype == torch.bool else mk, 1)
         b.t["kpm_used"] = kpm
         for l in range(L):
             lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
@@ -448,8 +449,8 @@ class DecoderEngine(_StackBase):
         b = self.buf((Bn, Te, S))
         self.cur, self.shape = b, (Bn, Te, S)
         b.t["ids"], b.t["mem"] = ids, mem
-        kpm = b.get("kpm", (Bn, Sd), torch.uint8)
-        torch.eq(ids[:, :-1], pad, out=kpm.view(torch.bool))
+        kpm = ("ids", ids, pad)          # tgt_padding_mask[:, :-1] == (ids[:, :Sd] == pad), evaluated inside the attention kernel
+        b.t["kpm"] = kpm
         y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
         logits = b.get("logits", (M, self.Vp), self.dt)
         ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, tag="gen_fwd")

@@ -136,7 +136,17 @@ def _attn_desc(dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout):
     d = L.AttnDesc()
     d.dtype, d.B, d.H, d.Lq, d.Lk, d.hd, d.causal = L.dtype_code(dtype), B, H, Lq, Lk, hd, int(causal)
     d.q, d.ldq, d.k, d.ldk, d.v, d.ldv = q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v)
-    d.key_pad = L.ptr(key_pad)
+    # key_pad: uint8/bool [B, Lk] | (mask [B, Lk - shift], shift) = first `shift` keys never padded | ("ids", ids [B, >=Lk] int64, pad_id)
+    if isinstance(key_pad, tuple) and key_pad[0] == "ids":
+        _tag, ids, pad_id = key_pad
+        assert ids.dtype == torch.int64 and ids.stride(1) == 1 and ids.shape[1] >= Lk
+        d.key_ids, d.key_ids_bs, d.pad_id = ids.data_ptr(), ids.stride(0), int(pad_id)
+    elif isinstance(key_pad, tuple):
+        m, shift = key_pad
+        assert m.is_contiguous() and m.element_size() == 1 and tuple(m.shape) == (B, Lk - shift)
+        d.key_pad, d.key_pad_shift = m.data_ptr(), int(shift)
+    else:
+        d.key_pad = L.ptr(key_pad)
     d.seed, d.site, d.p_drop = _drop(dropout)
     return d
 
