@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--overlap-adam", action="store_true", help="A/B: Adam per gradient bucket on the side stream during backward (measured slower)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-overlap-kv", action="store_true", help="A/B: cross-attention K/V projections and d(memory) GEMMs on the main stream")
+    ap.add_argument("--no-overlap-enc", action="store_true", help="A/B: encoder backward after (not beside) the decoder's tail")
     ap.add_argument("--no-group-dw", action="store_true", help="A/B: one launch per weight-gradient GEMM instead of one per layer")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
@@ -125,6 +126,8 @@ def main():
     if args.no_overlap_kv:
         from vct_amd import engine as _eng
         _eng._StackBase.overlap_kv = False
+    if args.no_overlap_enc:
+        MMT4Caption.overlap_enc_bwd = False
     if args.no_group_dw:
         from vct_amd import engine as _eng
         _eng._StackBase.group_dw = False

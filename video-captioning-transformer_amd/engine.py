@@ -151,7 +151,10 @@ class _StackBase:
         if cls._side is None:
             cls._side = torch.cuda.Stream(device=self.dev)
             cls._side_ws = ops.GemmScratch(self.dev)
-        cls._side.wait_stream(torch.cuda.current_stream())
+        cur = torch.cuda.current_stream()
+        if cur == cls._side:              # already running on the side stream (encoder backward beside the decoder's tail)
+            return fn(cls._side_ws)
+        cls._side.wait_stream(cur)
         with torch.cuda.stream(cls._side):
             return fn(cls._side_ws)
 
@@ -178,7 +181,7 @@ class _StackBase:
         LayerNorm/bias gradients (main stream) while the main stream goes straight on to the next layer."""
         self.flush_dw()
         side = _StackBase._side
-        if side is None or not self.overlap_dw:
+        if side is None or not self.overlap_dw or torch.cuda.current_stream() == side:
             return bucket_ready(*args)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -188,7 +191,7 @@ class _StackBase:
         """Main stream waits for every weight-gradient GEMM issued so far (before a gradient bucket is
         handed to the exchange / the optimizer)."""
         self.flush_dw()
-        if _StackBase._side is not None and self.overlap_dw:
+        if _StackBase._side is not None and self.overlap_dw and torch.cuda.current_stream() != _StackBase._side:
             torch.cuda.current_stream().wait_stream(_StackBase._side)
 
     def buf(self, key) -> _Buf:
@@ -473,9 +476,11 @@ class DecoderEngine(_StackBase):
         ops.gemm(last, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
         return logits[:, :self.V]
 
-    def backward(self, bucket_ready=None) -> torch.Tensor:
+    def backward(self, bucket_ready=None, on_dmem_ready=None) -> torch.Tensor:
         """d(loss) = 1.  Returns d(memory) [B*Te, d].  bucket_ready(kind, layer) is called when a gradient bucket
-        of MMT4Caption.grad_buckets() is complete ('generator', 'dec_layer' l, 'embedding')."""
+        of MMT4Caption.grad_buckets() is complete ('generator', 'dec_layer' l, 'embedding').  on_dmem_ready(dmem) is
+        called as soon as the last cross-attention backward has been enqueued -- d(memory) is final there, while the
+        bottom layer's self-attention backward and the embedding gradient are still to come."""
         b = self.cur
         Bn, Te, S = self.shape
         d, L, pad = self.cfg["d"], self.cfg["layers"], self.cfg["pad_id"]
@@ -498,6 +503,8 @@ class DecoderEngine(_StackBase):
             ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
             dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
+            if l == 0 and on_dmem_ready is not None:
+                on_dmem_ready(dmem)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
             self.flush_dw()               # this layer's weight gradients: one grouped launch beside the next layer
@@ -505,10 +512,10 @@ class DecoderEngine(_StackBase):
                 self.flush_ln_grads(b)
                 self.bucket_on_side(bucket_ready, "dec_layer", l)
         self.flush_ln_grads(b)
-        self.join_side()
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
         if bucket_ready is not None:
             bucket_ready("embedding")
+        self.join_side()
         return dmem
 
 

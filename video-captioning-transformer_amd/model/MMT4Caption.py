@@ -40,6 +40,8 @@ class _CaptionFn(torch.autograd.Function):
 
 
 class MMT4Caption(nn.Module):
+    overlap_enc_bwd = True      # encoder backward on the side stream beside the decoder's tail (A/B switch)
+
     def __init__(self, model_config: dict, device=torch.device("cuda"), compute_dtype=None):
         super().__init__()
         self.device = device
@@ -147,8 +149,20 @@ class MMT4Caption(nn.Module):
         if bucket_ready is not None:
             def hook(kind, layer=0):
                 bucket_ready(self.bucket_index(kind, layer))
-        dmem = self.cap_decoder._engine().backward(hook)
-        self.video_encoder._engine().backward(dmem, hook)
+        dec, enc = self.cap_decoder._engine(), self.video_encoder._engine()
+        if self.overlap_enc_bwd and dec.dev.type == "cuda" and dec.overlap_dw:
+            # the encoder's backward only needs d(memory): it runs on the side stream beside the decoder's bottom
+            # self-attention backward and the embedding gradient (two chains of small kernels share the chip)
+            from ..engine import _StackBase
+
+            def on_dmem(dmem):
+                dec._on_side(lambda ws: None)                     # makes sure the side stream exists and trails the main one
+                with torch.cuda.stream(_StackBase._side):
+                    enc.backward(dmem, hook)
+            dec.backward(hook, on_dmem_ready=on_dmem)             # ends with the main stream joining the side stream
+        else:
+            dmem = dec.backward(hook)
+            enc.backward(dmem, hook)
 
     def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor,
                            bucket_ready=None) -> torch.Tensor:
