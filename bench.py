@@ -128,6 +128,9 @@ def main():
         _eng._StackBase.overlap_kv = False
     if args.no_overlap_enc:
         MMT4Caption.overlap_enc_bwd = False
+        MMT4Caption.overlap_dec_prefix = False
+    if os.environ.get("VCT_NO_DEC_PREFIX"):
+        MMT4Caption.overlap_dec_prefix = False
     if args.no_group_dw:
         from vct_amd import engine as _eng
         _eng._StackBase.group_dw = False

@@ -118,6 +118,7 @@ class _StackBase:
         self._ln_pending = []
         self._dw_pending = []
         self._kv_prefetched = None
+        self._prefix = None
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
     def W(self, k): return self.ps.c[self.pre + k]
@@ -423,17 +424,50 @@ class DecoderEngine(_StackBase):
         self.V = cfg["vocab"]
         self.Vp = (self.V + 31) // 32 * 32
 
+    def _embed(self, b, ids, Sd, M):
+        return ops.embed_fwd(ids, Sd, self.F("tgt_to_emb.weight"), self.pos, b.get("x0", (M, self.cfg["d"]), self.dt),
+                             dropout=self.drop(EMB_SITE))
+
+    def _self_block(self, b, l, x, Bn, Sd, kpm):
+        """x1 = LN1(x + drop(SelfMHA(x))) of decoder layer l."""
+        lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
+        b.t[tag + "x"] = x
+        a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, Bn, Sd, Sd, True, kpm, site + 1)
+        return self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+
+    def forward_prefix(self, Bn: int, Te: int, ids: torch.Tensor, training: bool):
+        """The part of the decoder forward that does not depend on the encoder memory -- token embedding and the bottom
+        layer's self-attention block -- issued on the side stream so that it runs beside the encoder forward
+        (MMT4Caption._forward_loss calls this BEFORE the encoder is enqueued; forward() picks the result up)."""
+        pad, S = self.cfg["pad_id"], ids.shape[1]
+        Sd, M = S - 1, Bn * (S - 1)
+        self.p_drop = self.cfg["dropout"] if training else 0.0
+        b = self.buf((Bn, Te, S))
+        kpm = ("ids", ids, pad)
+
+        def run(_ws):
+            x = self._embed(b, ids, Sd, M)
+            return x, self._self_block(b, 0, x, Bn, Sd, kpm)
+        x, x1 = self._on_side(run)
+        self._prefix = (b, x, x1)
+
     def _run_stack(self, b, mem, Bn, Te, ids, Sd, kpm):
         """Embedding + decoder layers + final LayerNorm over the first Sd tokens of each ids row."""
         d, L = self.cfg["d"], self.cfg["layers"]
         M = Bn * Sd
         self.prefetch_cross_kv(b, mem, [(f"L{l}.ca.", f"decoder.layers.{l}.multihead_attn.") for l in range(L)])
-        x = ops.embed_fwd(ids, Sd, self.F("tgt_to_emb.weight"), self.pos, b.get("x0", (M, d), self.dt), dropout=self.drop(EMB_SITE))
+        prefix, self._prefix = self._prefix, None
+        if prefix is not None and prefix[0] is b:        # embedding + bottom self-attention already ran beside the encoder
+            x, x1_0 = prefix[1], prefix[2]
+            self.join_side()
+        else:
+            x, x1_0 = self._embed(b, ids, Sd, M), None
         for l in range(L):
             lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
-            b.t[tag + "x"] = x
-            a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, Bn, Sd, Sd, True, kpm, site + 1)
-            x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+            if l == 0 and x1_0 is not None:
+                x1 = x1_0
+            else:
+                x1 = self._self_block(b, l, x, Bn, Sd, kpm)
             c = self._attn_block_fwd(b, tag + "ca.", lp + "multihead_attn.", x1, mem, Bn, Sd, Te, False, None, site + 3, self_attn=False)
             x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, site + 4)
             f = self._ffn_fwd(b, tag + "ff.", lp, x2, site + 5)

@@ -40,7 +40,8 @@ class _CaptionFn(torch.autograd.Function):
 
 
 class MMT4Caption(nn.Module):
-    overlap_enc_bwd = True      # encoder backward on the side stream beside the decoder's tail (A/B switch)
+    overlap_enc_bwd = True      # encoder backward beside the decoder's tail (A/B switch)
+    overlap_dec_prefix = True   # decoder embedding + bottom self-attention beside the encoder forward (A/B switch)
 
     def __init__(self, model_config: dict, device=torch.device("cuda"), compute_dtype=None):
         super().__init__()
@@ -140,6 +141,9 @@ class MMT4Caption(nn.Module):
             self._build_flat()
         self._ps.refresh_shadow()
         enc, dec = self.video_encoder._engine(), self.cap_decoder._engine()
+        if self.overlap_dec_prefix and dec.dev.type == "cuda" and dec.overlap_dw:
+            # token embedding + the decoder's bottom self-attention block do not need the encoder: side stream, beside it
+            dec.forward_prefix(feats.shape[0], feats.shape[1] + 1, ids, training)
         mem = enc.forward(feats, mask, training)
         loss, logits = dec.forward(mem, feats.shape[0], feats.shape[1] + 1, ids, training, want_logits=want_logits)
         return loss, logits
