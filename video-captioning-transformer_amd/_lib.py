@@ -110,7 +110,7 @@ def _ensure_current():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         stamp = os.path.join(_PKG, "build", "stamp")
-        fresh = os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == mod._digest()
+        fresh = os.path.exists(LIB_PATH) and mod._read(stamp) == mod._digest()
         if not fresh and os.path.exists(mod._hipcc()):
             import fcntl
             import sys
@@ -118,7 +118,7 @@ def _ensure_current():
             with open(os.path.join(_PKG, "build", "lock"), "w") as lk:     # one rank of a multi-process launch builds
                 fcntl.flock(lk, fcntl.LOCK_EX)
                 try:
-                    if not (os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == mod._digest()):
+                    if not (os.path.exists(LIB_PATH) and mod._read(stamp) == mod._digest()):
                         print("[vct_amd] libvct_hip.so is missing or older than csrc/: rebuilding with hipcc ...", file=sys.stderr)
                         mod.build_library()
                 finally:

@@ -17,13 +17,21 @@ def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _read(path):
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return f.read()
+
+
 def _digest():
     h = hashlib.sha256()
     for fn in sorted(os.listdir(CSRC)) + ["../../include/vct_hip.h"]:
         p = os.path.join(CSRC, fn)
         if os.path.isfile(p):
             h.update(fn.encode())
-            h.update(open(p, "rb").read())
+            with open(p, "rb") as f:
+                h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
@@ -32,7 +40,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every csrc/*.hip for gfx950 and link libvct_hip.so next to this file."""
     stamp = os.path.join(PKG, "build", "stamp")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and os.path.exists(LIB) and _read(stamp) == dig:
         return LIB
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -169,11 +169,14 @@ class _StackBase:
         self._on_side(lambda ws: ops.gemm(dy, x, dw, ta=True, tb=False, bias_grad=bias_grad, m_valid=m_valid, tag=tag,
                                           workspace=ws))
 
-    def flush_dw(self):
-        """Issue the queued weight-gradient GEMMs as one grouped launch."""
+    def flush_dw(self, main: bool = False):
+        """Issue the queued weight-gradient GEMMs as one grouped launch (side stream, or the current one if `main`)."""
         if self._dw_pending:
             items, self._dw_pending = self._dw_pending, []
-            self._on_side(lambda ws: ops.gemm_grouped(items, ws))
+            if main:
+                ops.gemm_grouped(items, self.gemm_ws())
+            else:
+                self._on_side(lambda ws: ops.gemm_grouped(items, ws))
 
     def bucket_on_side(self, bucket_ready, *args):
         """Hand a finished gradient bucket to `bucket_ready` WITHOUT stalling the dX chain: the hook runs with the
@@ -510,7 +513,7 @@ class DecoderEngine(_StackBase):
         ops.gemm(last, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V)
         return logits[:, :self.V]
 
-    def backward(self, bucket_ready=None, on_dmem_ready=None) -> torch.Tensor:
+    def backward(self, bucket_ready=None, on_dmem_ready=None, join: bool = True) -> torch.Tensor:
         """d(loss) = 1.  Returns d(memory) [B*Te, d].  bucket_ready(kind, layer) is called when a gradient bucket
         of MMT4Caption.grad_buckets() is complete ('generator', 'dec_layer' l, 'embedding').  on_dmem_ready(dmem) is
         called as soon as the last cross-attention backward has been enqueued -- d(memory) is final there, while the
@@ -537,10 +540,26 @@ class DecoderEngine(_StackBase):
             ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
             dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
+            early = None
             if l == 0 and on_dmem_ready is not None:
+                # the bottom layer's weight gradients queued so far (FFN, cross-attention) go out BEFORE the encoder
+                # backward takes over the side stream; the two self-attention ones follow on the main stream, so this
+                # layer's gradients never wait for the encoder
+                self.flush_dw()
+                if _StackBase._side is not None and self.overlap_dw:
+                    early = torch.cuda.Event()
+                    early.record(_StackBase._side)
                 on_dmem_ready(dmem)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
+            if l == 0 and on_dmem_ready is not None:
+                self.flush_dw(main=True)
+                if early is not None:
+                    torch.cuda.current_stream().wait_event(early)
+                if bucket_ready is not None:
+                    self.flush_ln_grads(b)
+                    bucket_ready("dec_layer", l)
+                continue
             self.flush_dw()               # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None:      # this layer's (and, for the top layer, the final norm's) gradients are complete
                 self.flush_ln_grads(b)
@@ -549,7 +568,8 @@ class DecoderEngine(_StackBase):
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
         if bucket_ready is not None:
             bucket_ready("embedding")
-        self.join_side()
+        if join:
+            self.join_side()
         return dmem
 
 

@@ -148,7 +148,17 @@ class MMT4Caption(nn.Module):
         loss, logits = dec.forward(mem, feats.shape[0], feats.shape[1] + 1, ids, training, want_logits=want_logits)
         return loss, logits
 
-    def _backward(self, bucket_ready=None):
+    @property
+    def encoder_param_begin(self) -> int:
+        """Flat offset where the encoder's parameters (and whatever follows them) start: everything before it -- generator,
+        decoder stack, token embedding -- has its final gradient before the encoder backward has finished."""
+        return self.grad_buckets()[2 + self.cap_decoder.cfg["layers"]][0]
+
+    def join_backward(self):
+        """Main stream waits for the side stream (the encoder backward when it ran beside the decoder's tail)."""
+        self.cap_decoder._engine().join_side()
+
+    def _backward(self, bucket_ready=None, join: bool = True):
         hook = None
         if bucket_ready is not None:
             def hook(kind, layer=0):
@@ -163,18 +173,18 @@ class MMT4Caption(nn.Module):
                 dec._on_side(lambda ws: None)                     # makes sure the side stream exists and trails the main one
                 with torch.cuda.stream(_StackBase._side):
                     enc.backward(dmem, hook)
-            dec.backward(hook, on_dmem_ready=on_dmem)             # ends with the main stream joining the side stream
+            dec.backward(hook, on_dmem_ready=on_dmem, join=join)  # join: ends with the main stream joining the side stream
         else:
             dmem = dec.backward(hook)
             enc.backward(dmem, hook)
 
     def train_step_kernels(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor,
-                           bucket_ready=None) -> torch.Tensor:
+                           bucket_ready=None, defer_join: bool = False) -> torch.Tensor:
         """Fast path used by the trainer and bench: forward + backward as one static kernel schedule
         (hipGraph-capturable, no autograd tape).  Gradients are WRITTEN (not accumulated) into the flat
         gradient buffer, whose views are installed as `.grad`.  Returns the loss tensor [1]."""
         loss, _ = self._forward_loss(feats, mask, ids, self.training)
-        self._backward(bucket_ready)
+        self._backward(bucket_ready, join=not defer_join)     # defer_join: the caller calls join_backward() itself
         return loss
 
     # ---- reference API -----------------------------------------------------------------------------

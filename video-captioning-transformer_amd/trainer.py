@@ -227,6 +227,15 @@ class CaptionTrainer:
             if _StackBase._side is not None:
                 torch.cuda.current_stream().wait_stream(_StackBase._side)
             self.opt.finish_ranges()
+        elif fused and feats.is_cuda and m.overlap_enc_bwd:
+            # the encoder backward is still running on the side stream when the decoder's tail is done: Adam on everything
+            # but the encoder (86 % of the parameters at cfg-B) fills that gap on the main stream, the rest follows the join
+            loss = m.train_step_kernels(feats, mask, ids, defer_join=True)
+            a = m.encoder_param_begin
+            self.opt.step_range(0, a)
+            m.join_backward()
+            self.opt.step_range(a, m._ps.total)
+            self.opt.finish_ranges()
         else:
             loss = m.train_step_kernels(feats, mask, ids)
             self.opt.step()
