@@ -118,6 +118,7 @@ class _StackBase:
         self._ln_pending = []
         self._dw_pending = []
         self._kv_prefetched = None
+        self._kv_inplace = set()
         self._prefix = None
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
@@ -145,13 +146,18 @@ class _StackBase:
     _side = None
     _side_ws = None
 
-    def _on_side(self, fn):
-        if not (self.overlap_dw and self.dev.type == "cuda"):
-            return fn(self.gemm_ws())
+    def ensure_side(self):
         cls = _StackBase
         if cls._side is None:
             cls._side = torch.cuda.Stream(device=self.dev)
             cls._side_ws = ops.GemmScratch(self.dev)
+        return cls._side
+
+    def _on_side(self, fn):
+        if not (self.overlap_dw and self.dev.type == "cuda"):
+            return fn(self.gemm_ws())
+        cls = _StackBase
+        self.ensure_side()
         cur = torch.cuda.current_stream()
         if cur == cls._side:              # already running on the side stream (encoder backward beside the decoder's tail)
             return fn(cls._side_ws)
@@ -232,7 +238,7 @@ class _StackBase:
         critical path; here it is either picked up (after joining that stream) or computed in place."""
         d = self.cfg["d"]
         kv = b.get(tag + "kv", (mem.shape[0], 2 * d), self.dt)
-        if self._kv_prefetched:
+        if self._kv_prefetched and tag not in self._kv_inplace:
             if self._kv_prefetched == "pending":
                 self.join_side()
                 self._kv_prefetched = "joined"
@@ -241,7 +247,7 @@ class _StackBase:
         return kv
 
     def prefetch_cross_kv(self, b, mem, tags_lps):
-        if not self.overlap_kv:
+        if not self.overlap_kv or not tags_lps:
             return
         d = self.cfg["d"]
         for tag, lp in tags_lps:
@@ -458,12 +464,17 @@ class DecoderEngine(_StackBase):
         """Embedding + decoder layers + final LayerNorm over the first Sd tokens of each ids row."""
         d, L = self.cfg["d"], self.cfg["layers"]
         M = Bn * Sd
-        self.prefetch_cross_kv(b, mem, [(f"L{l}.ca.", f"decoder.layers.{l}.multihead_attn.") for l in range(L)])
         prefix, self._prefix = self._prefix, None
         if prefix is not None and prefix[0] is b:        # embedding + bottom self-attention already ran beside the encoder
             x, x1_0 = prefix[1], prefix[2]
+            # the main stream has nothing else to do until the bottom cross-attention: its K/V projection runs here, in
+            # place (no cross-stream hand-over on the critical path); the upper layers' go to the side stream
             self.join_side()
+            self.prefetch_cross_kv(b, mem, [(f"L{l}.ca.", f"decoder.layers.{l}.multihead_attn.") for l in range(1, L)])
+            self._kv_inplace = {"L0.ca."}
         else:
+            self.prefetch_cross_kv(b, mem, [(f"L{l}.ca.", f"decoder.layers.{l}.multihead_attn.") for l in range(L)])
+            self._kv_inplace = set()
             x, x1_0 = self._embed(b, ids, Sd, M), None
         for l in range(L):
             lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
@@ -540,7 +551,7 @@ class DecoderEngine(_StackBase):
             ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
             dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
-            early = None
+            early = dmem_point = None
             if l == 0 and on_dmem_ready is not None:
                 # the bottom layer's weight gradients queued so far (FFN, cross-attention) go out BEFORE the encoder
                 # backward takes over the side stream; the two self-attention ones follow on the main stream, so this
@@ -549,7 +560,11 @@ class DecoderEngine(_StackBase):
                 if _StackBase._side is not None and self.overlap_dw:
                     early = torch.cuda.Event()
                     early.record(_StackBase._side)
-                on_dmem_ready(dmem)
+                # d(memory) is final once everything enqueued so far has run: remember that point; the encoder backward is
+                # ENQUEUED after this layer's short tail (the host needs ~0.3 ms to launch its ~35 kernels, during which the
+                # main stream would starve) but only WAITS for this point
+                dmem_point = torch.cuda.Event()
+                dmem_point.record(torch.cuda.current_stream())
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
             if l == 0 and on_dmem_ready is not None:
@@ -559,7 +574,14 @@ class DecoderEngine(_StackBase):
                 if bucket_ready is not None:
                     self.flush_ln_grads(b)
                     bucket_ready("dec_layer", l)
-                continue
+                self.flush_ln_grads(b)
+                ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
+                if bucket_ready is not None:
+                    bucket_ready("embedding")
+                on_dmem_ready(dmem, dmem_point)           # the encoder backward goes to the side stream now
+                if join:
+                    self.join_side()
+                return dmem
             self.flush_dw()               # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None:      # this layer's (and, for the top layer, the final norm's) gradients are complete
                 self.flush_ln_grads(b)

@@ -155,8 +155,15 @@ class MMT4Caption(nn.Module):
         return self.grad_buckets()[2 + self.cap_decoder.cfg["layers"]][0]
 
     def join_backward(self):
-        """Main stream waits for the side stream (the encoder backward when it ran beside the decoder's tail)."""
+        """train_step_kernels(defer_join=True) leaves the encoder backward un-enqueued: enqueue it (side stream) if that
+        has not happened yet, then make the main stream wait for it."""
+        self.launch_encoder_backward()
         self.cap_decoder._engine().join_side()
+
+    def launch_encoder_backward(self):
+        fn, self._pending_enc_bwd = getattr(self, "_pending_enc_bwd", None), None
+        if fn is not None:
+            fn()
 
     def _backward(self, bucket_ready=None, join: bool = True):
         hook = None
@@ -169,10 +176,17 @@ class MMT4Caption(nn.Module):
             # self-attention backward and the embedding gradient (two chains of small kernels share the chip)
             from ..engine import _StackBase
 
-            def on_dmem(dmem):
-                dec._on_side(lambda ws: None)                     # makes sure the side stream exists and trails the main one
-                with torch.cuda.stream(_StackBase._side):
+            def launch(dmem, dmem_point):
+                side = dec.ensure_side()
+                side.wait_event(dmem_point)                       # d(memory) final (its last accumulate is on `side` itself)
+                with torch.cuda.stream(side):
                     enc.backward(dmem, hook)
+
+            def on_dmem(dmem, dmem_point):
+                if join:
+                    launch(dmem, dmem_point)
+                else:      # the caller enqueues its own main-stream work first (the host launches ~35 kernels here)
+                    self._pending_enc_bwd = lambda: launch(dmem, dmem_point)
             dec.backward(hook, on_dmem_ready=on_dmem, join=join)  # join: ends with the main stream joining the side stream
         else:
             dmem = dec.backward(hook)

@@ -232,7 +232,8 @@ class CaptionTrainer:
             # but the encoder (86 % of the parameters at cfg-B) fills that gap on the main stream, the rest follows the join
             loss = m.train_step_kernels(feats, mask, ids, defer_join=True)
             a = m.encoder_param_begin
-            self.opt.step_range(0, a)
+            self.opt.step_range(0, a)            # enqueued BEFORE the encoder backward: one launch vs ~35
+            m.launch_encoder_backward()
             m.join_backward()
             self.opt.step_range(a, m._ps.total)
             self.opt.finish_ranges()
