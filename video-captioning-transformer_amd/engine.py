@@ -551,26 +551,20 @@ class DecoderEngine(_StackBase):
             ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
             dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,
                                        False, ds2, dkv_out=dmem, dkv_accumulate=(l != L - 1))
-            early = dmem_point = None
+            dmem_point = None
             if l == 0 and on_dmem_ready is not None:
-                # the bottom layer's weight gradients queued so far (FFN, cross-attention) go out BEFORE the encoder
-                # backward takes over the side stream; the two self-attention ones follow on the main stream, so this
-                # layer's gradients never wait for the encoder
-                self.flush_dw()
-                if _StackBase._side is not None and self.overlap_dw:
-                    early = torch.cuda.Event()
-                    early.record(_StackBase._side)
                 # d(memory) is final once everything enqueued so far has run: remember that point; the encoder backward is
                 # ENQUEUED after this layer's short tail (the host needs ~0.3 ms to launch its ~35 kernels, during which the
                 # main stream would starve) but only WAITS for this point
                 dmem_point = torch.cuda.Event()
                 dmem_point.record(torch.cuda.current_stream())
+                # the bottom layer's weight gradients run on the MAIN stream (whose tail is not the critical path any
+                # more): the side stream is free for the encoder backward the moment d(memory) is final
+                self.flush_dw(main=True)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
             if l == 0 and on_dmem_ready is not None:
                 self.flush_dw(main=True)
-                if early is not None:
-                    torch.cuda.current_stream().wait_event(early)
                 if bucket_ready is not None:
                     self.flush_ln_grads(b)
                     bucket_ready("dec_layer", l)
