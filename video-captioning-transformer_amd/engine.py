@@ -143,6 +143,7 @@ class _StackBase:
     overlap_dw = True
     group_dw = True
     overlap_kv = True      # cross-attention K/V projections and d(memory) accumulation off the critical path
+    defer_gen_dw = True    # single GPU: vocabulary weight gradient at the end of the main stream's tail (A/B switch)
     _side = None
     _side_ws = None
 
@@ -537,8 +538,20 @@ class DecoderEngine(_StackBase):
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
         ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
-        self.dw_gemm(dl, y, self.G("generator.weight"), bias_grad=self.G("generator.bias"), m_valid=self.V,
-                     tag="gen_dw")
+        # the vocabulary weight gradient: with a gradient exchange it goes out first (its bucket is a third of the bytes and
+        # can be on the wire during the whole backward); without one and with the encoder backward on the side stream it
+        # is DEFERRED to the end of the main stream's tail, where that stream would otherwise idle -- beside the decoder's
+        # dX chain it slowed the critical path (a 34 us GEMM took 123 us next to it)
+        defer_gen_dw = self.defer_gen_dw and bucket_ready is None and on_dmem_ready is not None
+
+        def gen_dw():
+            if defer_gen_dw:
+                ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
+                         tag="gen_dw", workspace=self.gemm_ws())
+            else:
+                self.dw_gemm(dl, y, self.G("generator.weight"), bias_grad=self.G("generator.bias"), m_valid=self.V, tag="gen_dw")
+        if not defer_gen_dw:
+            gen_dw()
         if bucket_ready is not None:
             self.bucket_on_side(bucket_ready, "generator")
         dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
@@ -572,6 +585,8 @@ class DecoderEngine(_StackBase):
                 ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
                 if bucket_ready is not None:
                     bucket_ready("embedding")
+                if defer_gen_dw:
+                    gen_dw()
                 on_dmem_ready(dmem, dmem_point)           # the encoder backward goes to the side stream now
                 if join:
                     self.join_side()
