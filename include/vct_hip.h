@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 2
+#define VCT_ABI_VERSION 3
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -214,11 +214,13 @@ int vct_gather_pad_rows(int out_dtype, int B, int Tmax, int E, const float* stor
  * embedding is gathered from the fp32 master; offsets relative to `param`).  n must be a multiple of 4.
  * A step may be applied range by range (each range as soon as its gradients are final, on a side stream):
  * pass bump_step = 0 for all ranges and finish with one call n = 0, bump_step = 1.
+ * hyper_dev: optional DEVICE fp32 [5] = {lr, beta1, beta2, eps, weight_decay}; when given it overrides the scalar
+ * arguments, so a captured graph / recorded launch list follows an LR schedule (scalars are frozen at record time).
  * --------------------------------------------------------------------------------------------- */
 int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
-                  void* stream);
+                  const float* hyper_dev, void* stream);
 
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */
@@ -237,6 +239,40 @@ int vct_greedy_select(int dtype, int rows, int cols, const void* x, int64_t ldx,
                       void* stream);
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host runtime: recorded launch lists, cross-stream ordering, live kernel timing (csrc/vct_runtime.hip).
+ * replaces: the Python interpreter + torch dispatcher that issue the reference's step op by op (train.py:119-131);
+ * there is no counterpart object in the reference.
+ *
+ * Launch list: between vct_cmdlist_begin and vct_cmdlist_end every vct_* call made ON THIS HOST THREAD is validated
+ * and planned as usual but its kernel launches (and memsets, sync points, taps) are RECORDED instead of executed --
+ * kernel, geometry, by-value argument copies and the stream they were aimed at.  vct_cmdlist_replay re-issues them in
+ * the recorded order with eager semantics: launches aimed at `main_stream` of _begin go to `main_stream` of _replay,
+ * every other stream is used as recorded (the caller keeps those streams alive).  Device pointers are baked: record
+ * against static buffers.  A list is not thread safe; one recording per thread at a time.
+ * --------------------------------------------------------------------------------------------- */
+int vct_cmdlist_create(void** out_list);
+int vct_cmdlist_destroy(void* list);
+int vct_cmdlist_begin(void* list, void* main_stream);
+int vct_cmdlist_end(void* list);
+int vct_cmdlist_replay(void* list, void* main_stream);
+int vct_cmdlist_size(void* list);     /* recorded commands */
+int vct_cmdlist_streams(void* list);  /* distinct streams seen while recording */
+/* Cross-stream ordering, recordable: `waiter` will not run work enqueued after this call before everything enqueued on
+ * `signal` so far has finished (event record + stream wait; replaces torch's Stream.wait_stream on the fast path). */
+int vct_stream_wait(void* waiter_stream, void* signal_stream);
+/* Named sync points 0..63: vct_sync_record marks "everything enqueued on `stream` so far"; a later vct_sync_wait on any
+ * stream waits for the most recent mark with that id. */
+int vct_sync_record(int id, void* stream);
+int vct_sync_wait(int id, void* stream);
+/* Live kernel timing with HIP events on the launch stream (bench.py's roofline block): vct_tap(tag, 0, s) / vct_tap(tag,
+ * 1, s) bracket a region of stream s; every bracket executed (eagerly or by a replay) while taps are enabled adds one
+ * (start, end) pair to tag's pool.  vct_tap_collect waits for the pairs, writes their elapsed milliseconds
+ * (<= cap values) and resets the tag.  tag 0..15.  Disabled taps cost nothing and are not recorded. */
+int vct_tap_enable(int on);
+int vct_tap(int tag, int phase, void* stream);
+int vct_tap_collect(int tag, float* ms_out, int cap);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == 2
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 3
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -97,3 +97,26 @@ def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvct_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         _lib.load()
+
+
+def test_runtime_entry_points_validate_arguments(lib_path):
+    """Launch lists / sync points / taps (csrc/vct_runtime.hip): argument errors are codes; an empty recording works
+    without a device."""
+    from vct_amd import _lib
+    lib = _lib.load()
+    assert lib.vct_cmdlist_create(None) == -1
+    h = ctypes.c_void_p()
+    assert lib.vct_cmdlist_create(ctypes.byref(h)) == 0 and h.value
+    assert lib.vct_cmdlist_end(h) == -1                      # not recording
+    assert lib.vct_cmdlist_begin(h, None) == 0
+    assert lib.vct_cmdlist_begin(h, None) == -1              # one recording per thread
+    assert lib.vct_cmdlist_replay(h, None) == -1             # still recording
+    assert lib.vct_cmdlist_end(h) == 0
+    assert lib.vct_cmdlist_size(h) == 0 and lib.vct_cmdlist_streams(h) == 1
+    assert lib.vct_cmdlist_replay(h, None) == 0              # nothing to issue
+    assert lib.vct_cmdlist_destroy(h) == 0
+    assert lib.vct_sync_record(64, None) == -1 and lib.vct_sync_wait(-1, None) == -1
+    assert lib.vct_stream_wait(None, None) == 0              # same stream: no edge needed
+    assert lib.vct_tap(16, 0, None) == -1 and lib.vct_tap(0, 2, None) == -1
+    assert lib.vct_tap(0, 0, None) == 0                      # taps disabled: no-op
+    assert lib.vct_tap_collect(0, None, 0) == 0

@@ -1,0 +1,139 @@
+"""Step executors and stream ordering (round-2 fixes):
+  * a recorded launch list replays bitwise what eager launches compute (dropout on, two streams, Adam);
+  * the side-stream -> Adam edge holds even when the side stream is artificially late;
+  * LR schedules reach the Adam kernel under hipGraph and launch-list replay (hyper-parameters live on the device);
+  * ragged shape sequences never free buffers that recordings point to (grow-only allocations);
+  * weight decay leaves parameters outside the caption path alone."""
+import pytest
+import torch
+
+from test_dist_gpu import MC, VOCAB
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _model(dtype=torch.bfloat16, dropout=0.3, seed=7):
+    from helpers import build_model
+    torch.manual_seed(seed)
+    mc = dict(MC)
+    mc["dropout"] = dropout
+    m = build_model(mc, VOCAB, DEV, dtype)
+    m.train()
+    return m
+
+
+def _batch(seed, B=6, T=7, S=9):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, T, 48, generator=g)
+    mask = torch.zeros(B, T, dtype=torch.bool); mask[1, T - 2:] = True
+    ids = torch.randint(3, VOCAB, (B, S), generator=g); ids[:, 0] = 101; ids[2, S - 3:] = 0
+    return feats.to(DEV), mask.to(DEV), ids.to(DEV)
+
+
+def _run(executor, steps=5, shapes=None, lr_of=None, dtype=torch.bfloat16):
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    m = _model(dtype)
+    m._seed.fill_(1234)
+    opt = FusedAdam(m, lr=1e-3)
+    tr = CaptionTrainer(m, opt, use_graph=executor == "graph", launch_list=executor == "list")
+    losses = []
+    for k in range(steps):
+        if lr_of is not None:
+            opt.param_groups[0]["lr"] = lr_of(k)
+        kw = {} if shapes is None else dict(zip(("B", "T", "S"), shapes[k % len(shapes)]))
+        losses.append(tr.step(*_batch(100 + k, **kw)).clone())
+    torch.cuda.synchronize()
+    return m.flat_params.clone(), torch.cat(losses), tr
+
+
+@pytest.mark.parametrize("executor", ["list", "graph"])
+def test_recorded_step_is_bitwise_the_eager_step(executor):
+    p0, l0, _ = _run("eager")
+    p1, l1, tr = _run(executor)
+    assert torch.equal(l0, l1)
+    assert torch.equal(p0, p1)
+    if executor == "list":
+        (ll, _loss), = tr._lists.values()
+        assert len(ll) > 50 and ll.n_streams == 2       # both streams and their edges were recorded
+
+
+@pytest.mark.parametrize("executor", ["eager", "list", "graph"])
+def test_lr_schedule_reaches_the_adam_kernel(executor):
+    """A different learning rate every step: replays must follow it (kernel scalars are frozen at record time)."""
+    sched = lambda k: 1e-3 * (0.5 ** k)
+    p_ref, _, _ = _run("eager", lr_of=sched)
+    p_const, _, _ = _run("eager")
+    p, _, _ = _run(executor, lr_of=sched)
+    assert torch.equal(p, p_ref)
+    assert not torch.equal(p_ref, p_const)
+
+
+def test_side_stream_gradients_are_final_before_adam_reads_them(monkeypatch):
+    """Delay the side stream (decoder weight gradients, d(memory) GEMMs) by ~20 ms each step: Adam on the main stream
+    must still see final gradients, i.e. the result equals the run without the delay."""
+    from vct_amd import engine
+    ref, lref, _ = _run("eager", steps=3)
+    orig = engine._StackBase.flush_dw
+    spins = {"n": 0}
+
+    def slow_flush(self, main=False):
+        if not main and self._dw_pending and engine._StackBase._side is not None:
+            with torch.cuda.stream(engine._StackBase._side):
+                torch.cuda._sleep(40_000_000)
+            spins["n"] += 1
+        return orig(self, main)
+    monkeypatch.setattr(engine._StackBase, "flush_dw", slow_flush)
+    got, lgot, _ = _run("eager", steps=3)
+    assert spins["n"] > 0
+    assert torch.equal(lref, lgot)
+    assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("executor", ["list", "graph"])
+def test_ragged_epoch_keeps_recordings_valid(executor):
+    """Eight shape configurations cycled twice (the loader trims S per batch): recordings of earlier shapes must stay
+    valid -- buffers only grow, and a growth drops every recording that baked the old pointers."""
+    shapes = [(6, 7, 9), (6, 7, 5), (4, 7, 8), (6, 5, 9), (6, 7, 7), (3, 6, 6), (6, 7, 10), (5, 7, 9)]
+    p0, l0, _ = _run("eager", steps=16, shapes=shapes)
+    p1, l1, tr = _run(executor, steps=16, shapes=shapes)
+    assert torch.equal(l0, l1)
+    assert torch.equal(p0, p1)
+    assert len(tr._lists if executor == "list" else tr._graphs) >= 2
+
+
+def test_weight_decay_spares_parameters_outside_the_caption_path():
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    m = _model(torch.float32, dropout=0.0)
+    assert m.caption_param_end < m._ps.total                 # matching.v_proj.* sit behind the caption parameters
+    before = m.flat_params.clone()
+    opt = FusedAdam(m, lr=1e-2, weight_decay=0.1)
+    CaptionTrainer(m, opt).step(*_batch(3))
+    torch.cuda.synchronize()
+    e = m.caption_param_end
+    assert torch.equal(m.flat_params[e:], before[e:])
+    assert not torch.equal(m.flat_params[:e], before[:e])
+
+
+def test_taps_time_kernels_inside_replays():
+    from vct_amd import ops
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    m = _model()
+    tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), launch_list=True)
+    ops.taps_enable(True)
+    try:
+        for k in range(4):
+            tr.step(*_batch(5))
+        torch.cuda.synchronize()
+        ms = ops.tap_collect("step")
+        gen = ops.tap_collect("gen_fwd")
+    finally:
+        ops.taps_enable(False)
+    assert len(ms) == 4 and all(0.0 < x < 1000.0 for x in ms)
+    assert len(gen) == 4 and all(0.0 < x <= y for x, y in zip(gen, ms))

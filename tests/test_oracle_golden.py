@@ -173,3 +173,30 @@ def test_cfgA_greedy_decode(golden_dir):
     assert ys.shape[1] <= ref.shape[1]
     assert float(z["margins"].min()) > 1e-4
     assert np.array_equal(ys, ref[:, :ys.shape[1]])
+
+
+def test_torch_cpu_baseline_model_matches_the_oracle():
+    """oracle/torch_ref.py (the module graph bench.py times as the CPU baseline) == the numpy oracle on a ragged batch:
+    loss, logits and every parameter gradient (dropout 0)."""
+    import torch
+    import torch_ref as TR
+    mc = {"modal_shape": [24], "embed_dim": 32, "activation": "gelu",
+          "video_encoder": {"layer": 2, "nhead": 4, "feedforward": 48},
+          "caption_decoder": {"layer": 2, "nhead": 4, "feedforward": 48, "sce_loss_alpha": 0.5}}
+    cfg = O.cfg_from_model_config(mc, 131)
+    p = O.init_params(cfg, seed=5)
+    feats, mask, ids = O.synthetic_batch(5, 6, 24, 8, 131, seed=2, ragged=True)
+    ref_loss, ref_grads, ref_logits = O.caption_loss_and_grads(p, cfg, feats, mask, ids)
+    torch.manual_seed(0)
+    m = TR.RefCaptionModel(cfg, dropout=0.0)
+    m.load_oracle_params(p)
+    m.train()
+    logits, loss = m(torch.from_numpy(feats), torch.from_numpy(mask), torch.from_numpy(ids))
+    loss.backward()
+    assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+    np.testing.assert_allclose(logits.detach().numpy().reshape(ref_logits.shape), ref_logits, rtol=2e-4, atol=2e-5)
+    named = dict(m.named_parameters())
+    for k, g in ref_grads.items():
+        mine = named[k].grad.numpy()
+        err = np.linalg.norm(mine - g) / max(np.linalg.norm(g), 1e-30)
+        assert err < 2e-4, (k, err)

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -59,7 +59,20 @@ _SIGS = {
     "vct_advance_seed": (C.c_int, [vp, vp]),
     "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
-    "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp]),
+    "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp]),
+    "vct_cmdlist_create": (C.c_int, [C.POINTER(vp)]),
+    "vct_cmdlist_destroy": (C.c_int, [vp]),
+    "vct_cmdlist_begin": (C.c_int, [vp, vp]),
+    "vct_cmdlist_end": (C.c_int, [vp]),
+    "vct_cmdlist_replay": (C.c_int, [vp, vp]),
+    "vct_cmdlist_size": (C.c_int, [vp]),
+    "vct_cmdlist_streams": (C.c_int, [vp]),
+    "vct_stream_wait": (C.c_int, [vp, vp]),
+    "vct_sync_record": (C.c_int, [C.c_int, vp]),
+    "vct_sync_wait": (C.c_int, [C.c_int, vp]),
+    "vct_tap_enable": (C.c_int, [C.c_int]),
+    "vct_tap": (C.c_int, [C.c_int, C.c_int, vp]),
+    "vct_tap_collect": (C.c_int, [C.c_int, C.POINTER(f32), C.c_int]),
 }
 _OPTIONAL = {}
 
@@ -123,9 +136,10 @@ def _ensure_current():
                         mod.build_library()
                 finally:
                     fcntl.flock(lk, fcntl.LOCK_UN)
-    except Exception as e:   # a failed rebuild surfaces below as "library missing" or as a load error
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"could not build libvct_hip.so: {e}")
+        elif not fresh and os.path.exists(LIB_PATH):
+            raise RuntimeError("csrc/ changed after libvct_hip.so was built and hipcc is not available to rebuild it")
+    except Exception as e:   # never fall through to a library that no longer matches csrc/
+        raise RuntimeError(f"libvct_hip.so is missing or stale and rebuilding it failed: {e}") from e
 
 
 def check(rc, what):

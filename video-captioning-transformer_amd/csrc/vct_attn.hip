@@ -479,8 +479,8 @@ template <typename T, int DT> static int attn_launch(const AttnP& p, bool bwd, h
     attr[bwd] = (int)lds;
   }
   const dim3 grid(p.B * p.H);
-  if (bwd) hipLaunchKernelGGL((attn_bwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
+  if (bwd) vct::launch((attn_bwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
+  else vct::launch((attn_fwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -6,6 +6,7 @@
 #include <utility>
 #include <type_traits>
 #include "../../include/vct_hip.h"
+#include "vct_runtime.h"
 
 namespace vct {
 

@@ -442,9 +442,9 @@ extern "C" int vct_enc_frontend_fwd(int dtype, int B, int T, int d, const void* 
   hipStream_t st = (hipStream_t)stream;
   const int threads = 128;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((enc_frontend_fwd_kernel<bf16_t>), dim3(B), dim3(threads), 0, st, B, T, d, (const bf16_t*)u, pe_rows, (bf16_t*)z);
+    vct::launch((enc_frontend_fwd_kernel<bf16_t>), dim3(B), dim3(threads), 0, st, B, T, d, (const bf16_t*)u, pe_rows, (bf16_t*)z);
   else
-    hipLaunchKernelGGL((enc_frontend_fwd_kernel<float>), dim3(B), dim3(threads), 0, st, B, T, d, (const float*)u, pe_rows, (float*)z);
+    vct::launch((enc_frontend_fwd_kernel<float>), dim3(B), dim3(threads), 0, st, B, T, d, (const float*)u, pe_rows, (float*)z);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -455,9 +455,9 @@ extern "C" int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* 
   if (d % vec_of(dtype)) return VCT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((enc_frontend_bwd_kernel<bf16_t>), dim3(B), dim3(128), 0, st, B, T, d, (const bf16_t*)dz, (bf16_t*)du);
+    vct::launch((enc_frontend_bwd_kernel<bf16_t>), dim3(B), dim3(128), 0, st, B, T, d, (const bf16_t*)dz, (bf16_t*)du);
   else
-    hipLaunchKernelGGL((enc_frontend_bwd_kernel<float>), dim3(B), dim3(128), 0, st, B, T, d, (const float*)dz, (float*)du);
+    vct::launch((enc_frontend_bwd_kernel<float>), dim3(B), dim3(128), 0, st, B, T, d, (const float*)dz, (float*)du);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -471,10 +471,10 @@ extern "C" int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids,
   hipStream_t st = (hipStream_t)stream;
   const int N = B * S;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
+    vct::launch((embed_fwd_kernel<bf16_t>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
                        (const float*)table, pos, (bf16_t*)x, seed, site, p_drop);
   else
-    hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
+    vct::launch((embed_fwd_kernel<float>), dim3((N + 3) / 4), dim3(256), 0, st, N, S, d, ids, id_batch_stride,
                        (const float*)table, pos, (float*)x, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
@@ -487,22 +487,22 @@ extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_
   if (B <= 0 || S <= 0 || d <= 0 || V <= 0) return VCT_E_SHAPE;
   if (d % vec_of(dtype) || d / vec_of(dtype) > 256) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dtable, 0, (size_t)V * d * sizeof(float), st);
+  hipError_t e = vct::memset_async(dtable, 0, (size_t)V * d * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   int32_t* first_pos = id_ws;
   int32_t* cnt = id_ws + V;
-  e = hipMemsetAsync(first_pos, 0x7f, (size_t)V * sizeof(int32_t), st);   // 0x7f7f7f7f: larger than any position
+  e = vct::memset_async(first_pos, 0x7f, (size_t)V * sizeof(int32_t), st);   // 0x7f7f7f7f: larger than any position
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(cnt, 0, (size_t)V * sizeof(int32_t), st);
+  e = vct::memset_async(cnt, 0, (size_t)V * sizeof(int32_t), st);
   if (e != hipSuccess) return (int)e;
   const int N = B * S;
-  hipLaunchKernelGGL(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt);
+  vct::launch(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt);
   VCT_CHECK_LAUNCH();
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
+    vct::launch((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
                        (const bf16_t*)dx, dtable, first_pos, cnt, seed, site, p_drop);
   else
-    hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
+    vct::launch((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
                        (const float*)dx, dtable, first_pos, cnt, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
@@ -519,17 +519,17 @@ extern "C" int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, 
   if (dlogits && (ld_dl < vround || ld_dl % vec || ((uintptr_t)dlogits & 15))) return VCT_E_ALIGN;
   if (ld_dl > (int64_t)8 * 1024 * vec || vround > (int64_t)8 * 1024 * vec) return VCT_E_SHAPE;   // row must fit the register tile
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, st, N, S, labels, label_batch_stride, pad_id, row_ws + 2 * (size_t)N);
+  vct::launch(count_valid_kernel, dim3(1), dim3(1024), 0, st, N, S, labels, label_batch_stride, pad_id, row_ws + 2 * (size_t)N);
   VCT_CHECK_LAUNCH();
   const int64_t width = dlogits ? (ld_dl > vround ? ld_dl : vround) : vround;
   const bool small = width <= (int64_t)4 * 1024 * vec;
-#define VCT_SCE(T_, IT_, NT_) hipLaunchKernelGGL((sce_loss_kernel<T_, IT_, NT_>), dim3(N), dim3(NT_), 0, st, N, S, V, (const T_*)logits, ldl, \
+#define VCT_SCE(T_, IT_, NT_) vct::launch((sce_loss_kernel<T_, IT_, NT_>), dim3(N), dim3(NT_), 0, st, N, S, V, (const T_*)logits, ldl, \
                                                  labels, label_batch_stride, pad_id, alpha, (T_*)dlogits, ld_dl, row_ws)
   if (dtype == VCT_BF16) { if (small) VCT_SCE(bf16_t, 4, 1024); else VCT_SCE(bf16_t, 8, 1024); }
   else { if (small) VCT_SCE(float, 4, 1024); else VCT_SCE(float, 8, 1024); }
 #undef VCT_SCE
   VCT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sce_finalize_kernel, dim3(1), dim3(1024), 0, st, N, alpha, row_ws, loss_out);
+  vct::launch(sce_finalize_kernel, dim3(1), dim3(1024), 0, st, N, alpha, row_ws, loss_out);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -541,13 +541,13 @@ extern "C" int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst
   const int64_t want = (n / 4 + 255) / 256;
   const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
   if (src_dtype == VCT_F32 && dst_dtype == VCT_BF16)
-    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    vct::launch((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
   else if (src_dtype == VCT_BF16 && dst_dtype == VCT_F32)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    vct::launch((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
   else if (src_dtype == VCT_F32)
-    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    vct::launch((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
   else
-    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    vct::launch((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -558,10 +558,10 @@ extern "C" int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int
   if (rows <= 0 || cols <= 0 || out_stride <= 0) return VCT_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
+    vct::launch((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
                        (int64_t)0, (uint8_t*)nullptr, (int32_t*)nullptr, (unsigned long long*)nullptr, 0);
   else
-    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
+    vct::launch((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
                        (int64_t)0, (uint8_t*)nullptr, (int32_t*)nullptr, (unsigned long long*)nullptr, 0);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
@@ -575,10 +575,10 @@ extern "C" int vct_greedy_select(int dtype, int rows, int cols, const void* x, i
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* at = reinterpret_cast<unsigned long long*>(all_ended_at);
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
+    vct::launch((argmax_rows_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, cols, (const bf16_t*)x, ldx, out, out_stride,
                        end_id, ended, ended_count, at, (int)t);
   else
-    hipLaunchKernelGGL((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
+    vct::launch((argmax_rows_kernel<float>), dim3(rows), dim3(256), 0, st, cols, (const float*)x, ldx, out, out_stride,
                        end_id, ended, ended_count, at, (int)t);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
@@ -592,16 +592,16 @@ extern "C" int vct_gather_pad_rows(int out_dtype, int B, int Tmax, int E, const 
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (B * Tmax + 3) / 4;
   if (out_dtype == VCT_BF16)
-    hipLaunchKernelGGL((gather_pad_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (bf16_t*)out, mask);
+    vct::launch((gather_pad_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (bf16_t*)out, mask);
   else
-    hipLaunchKernelGGL((gather_pad_rows_kernel<float>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (float*)out, mask);
+    vct::launch((gather_pad_rows_kernel<float>), dim3(blocks), dim3(256), 0, st, store, offsets, idx, B, Tmax, E, (float*)out, mask);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
 
 extern "C" int vct_advance_seed(uint32_t* seed, void* stream) {
   if (!seed) return VCT_E_ARG;
-  hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+  vct::launch(advance_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

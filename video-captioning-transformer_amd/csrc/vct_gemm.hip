@@ -363,7 +363,7 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
 
 template <typename TI, typename TO, int TA, int TB, int BM>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_kernel<TI, TO, TA, TB, BM, BM>), grid, dim3(256), 0, st, p);
+  vct::launch((gemm_kernel<TI, TO, TA, TB, BM, BM>), grid, dim3(256), 0, st, p);
 }
 
 template <typename TI, typename TO>
@@ -465,10 +465,10 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
     const size_t total = (size_t)d->M * d->N;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (d->out_dtype == VCT_F32)
-      hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p.partial,
+      vct::launch((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p.partial,
                          reinterpret_cast<float*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
     else
-      hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p.partial,
+      vct::launch((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p.partial,
                          reinterpret_cast<bf16_t*>(d->C), (long)d->ldc, d->M, d->N, pl.split, p.bias_partial, d->bias_grad);
     VCT_CHECK_LAUNCH();
   }

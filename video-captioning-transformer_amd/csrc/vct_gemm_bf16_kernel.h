@@ -479,9 +479,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, WGM * WGN)) 
 
 template <typename TO, int TA, int TB, int NBUF>
 static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t st) {
-#define VCT_LAUNCH(BM_, BN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
+#define VCT_LAUNCH(BM_, BN_) vct::launch((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF>), grid, dim3(256), 0, st, p)
   if (p.waves8) {   // eight-wave variants: waves8 = variant id
-#define VCT_LW(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
+#define VCT_LW(BM_, BN_, WM_, WN_) vct::launch((gemm_bf16_v2_kernel<TO, TA, TB, BM_, BN_, NBUF, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, p)
     // measured (tools/gemm_bench.py): 16-wave 128x128, 8-wave 64x64 and every 256-wide tile (256x256 with 8 or 16 waves,
     // 256x128 with 8 waves, single or double buffered: 320-570 TF where 128x128 gives 550-780) lose to these two everywhere
     if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);

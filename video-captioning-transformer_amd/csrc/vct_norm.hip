@@ -251,10 +251,10 @@ extern "C" int vct_add_ln_fwd(int dtype, int M, int d, const void* x, const void
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((M + 3) / 4);
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)x, (const bf16_t*)res,
+    vct::launch((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)x, (const bf16_t*)res,
                        gamma, beta, (bf16_t*)y, mean, rstd, seed, site, p_drop);
   else
-    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)x, (const float*)res,
+    vct::launch((add_ln_fwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)x, (const float*)res,
                        gamma, beta, (float*)y, mean, rstd, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
@@ -272,14 +272,14 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
   const int nws = vct_ln_ws_rows(M);
   const dim3 grid(nws);
   if (dtype == VCT_BF16)
-    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
+    vct::launch((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
                        (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop);
   else
-    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
+    vct::launch((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
                        (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   if (dgamma != nullptr && dbeta != nullptr) {   // NULL: the caller finalizes later with vct_ln_param_finalize_batched
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
+    vct::launch(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
     VCT_CHECK_LAUNCH();
   }
   return VCT_OK;
@@ -288,7 +288,7 @@ extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const voi
 extern "C" int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream) {
   if (!table_dev) return VCT_E_ARG;
   if (n_entries <= 0 || d <= 0) return VCT_E_SHAPE;
-  hipLaunchKernelGGL(ln_param_finalize_batched_kernel, dim3((2 * d + 15) / 16, n_entries), dim3(256), 0, (hipStream_t)stream,
+  vct::launch(ln_param_finalize_batched_kernel, dim3((2 * d + 15) / 16, n_entries), dim3(256), 0, (hipStream_t)stream,
                      table_dev, d);
   VCT_CHECK_LAUNCH();
   return VCT_OK;

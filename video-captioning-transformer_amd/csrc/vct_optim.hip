@@ -11,7 +11,10 @@ namespace vct {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, const int32_t* __restrict__ step,
-                                                   int64_t skip_a, int64_t skip_b) {
+                                                   int64_t skip_a, int64_t skip_b, const float* __restrict__ hyper) {
+  // hyper-parameters from DEVICE memory when given: a captured hipGraph / recorded launch list then follows the
+  // learning-rate schedule (kernel arguments are frozen at capture time)
+  if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
   const float t = (float)(step[0] + 1);
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2s = sqrtf(1.0f - powf(b2, t));
@@ -53,22 +56,22 @@ using namespace vct;
 extern "C" int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                              int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
-                             void* stream) {
+                             const float* hyper_dev, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return VCT_E_ARG;
   if (n < 0 || (n & 3)) return VCT_E_SHAPE;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VCT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {   // bump only
-    if (bump_step) { hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev); VCT_CHECK_LAUNCH(); }
+    if (bump_step) { vct::launch(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev); VCT_CHECK_LAUNCH(); }
     return VCT_OK;
   }
   const int64_t want = ((n >> 2) + 255) / 256;
   const int blocks = (int)(want > 8192 ? 8192 : want);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end);
+  vct::launch(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
+                     beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end, hyper_dev);
   VCT_CHECK_LAUNCH();
   if (bump_step) {
-    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    vct::launch(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
     VCT_CHECK_LAUNCH();
   }
   return VCT_OK;

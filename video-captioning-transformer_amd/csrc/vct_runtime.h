@@ -1,0 +1,33 @@
+// Launch layer shared by every kernel file: a launch either goes straight to the stream (eager) or, while a launch
+// list is being recorded on this host thread, is appended to that list as a closure holding the kernel, its geometry
+// and BY-VALUE copies of its arguments.  Replaying the list re-issues exactly those launches -- no planning, no
+// descriptor marshalling, no Python -- with eager multi-stream semantics (each entry remembers its stream, cross-stream
+// edges are recorded event record / wait pairs).  See vct_runtime.hip and include/vct_hip.h (vct_cmdlist_*).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <functional>
+
+namespace vct {
+
+struct CmdList;
+extern thread_local CmdList* g_rec;                                           // non-null while this thread records
+void rec_push(hipStream_t st, std::function<void(hipStream_t)>&& fn);         // append to g_rec
+
+template <typename K, typename... A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  if (g_rec != nullptr) {
+    rec_push(st, [=](hipStream_t s) { hipLaunchKernelGGL(kernel, grid, block, lds, s, args...); });
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
+}
+
+inline hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t st) {
+  if (g_rec != nullptr) {
+    rec_push(st, [=](hipStream_t s) { (void)hipMemsetAsync(p, value, bytes, s); });
+    return hipSuccess;
+  }
+  return hipMemsetAsync(p, value, bytes, st);
+}
+
+}  // namespace vct

@@ -21,6 +21,7 @@ import torch
 from . import ops
 
 ENC_SITE, DEC_SITE, EMB_SITE = 0, 1000, 999
+DMEM_SYNC = 0      # named sync point (ops.sync_record / sync_wait): d(memory) is final on the main stream
 
 
 class ParamSet:
@@ -95,16 +96,30 @@ class ParamSet:
 
 
 class _Buf:
-    """Named, lazily allocated device buffers of one shape configuration (static addresses)."""
+    """Named device buffers with STATIC addresses.  One instance serves every shape configuration of an engine:
+    `get` hands out a leading view of a per-name allocation that only ever grows, so a ragged epoch (the loader trims S
+    to each batch's longest caption) neither re-allocates per step nor frees memory that a captured hipGraph / recorded
+    launch list still points to.  `generation` counts (re)allocations: whoever bakes pointers (trainer graphs, launch
+    lists, pointer tables) keys its cache on it and re-records after a growth."""
+
+    generation = 0          # class-wide: any growth anywhere invalidates every baked pointer set
 
     def __init__(self, device):
-        self.device, self.t = device, {}
+        self.device, self.t, self._store = device, {}, {}
 
     def get(self, name, shape, dtype):
-        t = self.t.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
-            self.t[name] = t
+        n = 1
+        for s in shape:
+            n *= int(s)
+        st = self._store.get(name)
+        if st is None or st.dtype != dtype or st.numel() < n:
+            st = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._store[name] = st
+            _Buf.generation += 1
+            for k in [k for k in self.t if isinstance(k, tuple) and k and k[0] == "ln_table"]:
+                del self.t[k]          # pointer tables baked the old addresses
+        t = st[:n].view(shape)
+        self.t[name] = t
         return t
 
 
@@ -162,7 +177,7 @@ class _StackBase:
         cur = torch.cuda.current_stream()
         if cur == cls._side:              # already running on the side stream (encoder backward beside the decoder's tail)
             return fn(cls._side_ws)
-        cls._side.wait_stream(cur)
+        ops.stream_wait(cls._side, cur)
         with torch.cuda.stream(cls._side):
             return fn(cls._side_ws)
 
@@ -194,7 +209,7 @@ class _StackBase:
         side = _StackBase._side
         if side is None or not self.overlap_dw or torch.cuda.current_stream() == side:
             return bucket_ready(*args)
-        side.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(side, None)
         with torch.cuda.stream(side):
             return bucket_ready(*args)
 
@@ -203,14 +218,14 @@ class _StackBase:
         handed to the exchange / the optimizer)."""
         self.flush_dw()
         if _StackBase._side is not None and self.overlap_dw and torch.cuda.current_stream() != _StackBase._side:
-            torch.cuda.current_stream().wait_stream(_StackBase._side)
+            ops.stream_wait(None, _StackBase._side)
 
     def buf(self, key) -> _Buf:
-        b = self.bufs.get(key)
+        """The engine's buffer set (`key` = the shape configuration, kept for diagnostics only: every configuration
+        shares one set of grow-only allocations, see _Buf)."""
+        b = self.bufs.get("all")
         if b is None:
-            if len(self.bufs) > 4:
-                self.bufs.clear()
-            b = self.bufs[key] = _Buf(self.dev)
+            b = self.bufs["all"] = _Buf(self.dev)
         return b
 
     # ---- shared sub-blocks -------------------------------------------------------------------
@@ -504,12 +519,15 @@ class DecoderEngine(_StackBase):
         kpm = ("ids", ids, pad)          # tgt_padding_mask[:, :-1] == (ids[:, :Sd] == pad), evaluated inside the attention kernel
         b.t["kpm"] = kpm
         y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
+        ops.tap("layers_fwd", 1)
         logits = b.get("logits", (M, self.Vp), self.dt)
         ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, tag="gen_fwd")
         loss = b.get("loss", (1,), torch.float32)
         dlogits = b.get("dlogits", (M, self.Vp), self.dt) if want_logits else logits
+        ops.tap("loss", 0)
         ops.sce_loss(logits, self.V, ids[:, 1:], Sd, pad, self.cfg["sce_loss_alpha"], loss, dlogits,
                      b.get("row_ws", (2 * M + 2,), torch.float32))
+        ops.tap("loss", 1)
         b.t["dlogits_used"] = dlogits
         return loss, (logits if want_logits else None)
 
@@ -569,8 +587,8 @@ class DecoderEngine(_StackBase):
                 # d(memory) is final once everything enqueued so far has run: remember that point; the encoder backward is
                 # ENQUEUED after this layer's short tail (the host needs ~0.3 ms to launch its ~35 kernels, during which the
                 # main stream would starve) but only WAITS for this point
-                dmem_point = torch.cuda.Event()
-                dmem_point.record(torch.cuda.current_stream())
+                dmem_point = DMEM_SYNC
+                ops.sync_record(dmem_point)
                 # the bottom layer's weight gradients run on the MAIN stream (whose tail is not the critical path any
                 # more): the side stream is free for the encoder backward the moment d(memory) is final
                 self.flush_dw(main=True)

@@ -11,6 +11,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..engine import ParamSet
 from .CapDecoder import CapDecoder, grad_ready_order_decoder
 from .CapPreprocessor import CapPreprocessor
@@ -141,6 +142,7 @@ class MMT4Caption(nn.Module):
             self._build_flat()
         self._ps.refresh_shadow()
         enc, dec = self.video_encoder._engine(), self.cap_decoder._engine()
+        ops.tap("layers_fwd", 0)      # bench.py north_star bracket: input cast .. decoder final LayerNorm (main stream)
         if self.overlap_dec_prefix and dec.dev.type == "cuda" and dec.overlap_dw:
             # token embedding + the decoder's bottom self-attention block do not need the encoder: side stream, beside it
             dec.forward_prefix(feats.shape[0], feats.shape[1] + 1, ids, training)
@@ -153,6 +155,16 @@ class MMT4Caption(nn.Module):
         """Flat offset where the encoder's parameters (and whatever follows them) start: everything before it -- generator,
         decoder stack, token embedding -- has its final gradient before the encoder backward has finished."""
         return self.grad_buckets()[2 + self.cap_decoder.cfg["layers"]][0]
+
+    @property
+    def caption_param_end(self) -> int:
+        """Flat offset where the parameters OUTSIDE the caption path (matching.*) start -- the end of what the caption
+        task's optimizer owns (reference train.py:24: filter(requires_grad) after mode('caption'))."""
+        ps = self._ps
+        for n in ps.names:
+            if not (n.startswith("cap_decoder.") or n.startswith("video_encoder.")):
+                return ps.offsets[n]
+        return ps.total
 
     def join_backward(self):
         """train_step_kernels(defer_join=True) leaves the encoder backward un-enqueued: enqueue it (side stream) if that
@@ -178,7 +190,7 @@ class MMT4Caption(nn.Module):
 
             def launch(dmem, dmem_point):
                 side = dec.ensure_side()
-                side.wait_event(dmem_point)                       # d(memory) final (its last accumulate is on `side` itself)
+                ops.sync_wait(dmem_point, side)                   # d(memory) final (its last accumulate is on `side` itself)
                 with torch.cuda.stream(side):
                     enc.backward(dmem, hook)
 

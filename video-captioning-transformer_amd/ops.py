@@ -8,9 +8,8 @@ from . import _lib as L
 
 Drop = Optional[Tuple[torch.Tensor, int, float]]  # (seed tensor uint32[1] on device, site id, p)
 
-# Optional live timing of tagged launches (bench.py roofline): event_taps[tag] = list of (start, end)
-# torch.cuda.Event pairs recorded on the launch stream around the kernel.  Empty dict = no overhead.
-event_taps = {}
+# Live timing of tagged launches (bench.py roofline): see taps_enable / tap / tap_collect at the end of this file --
+# HIP event pairs recorded by the C runtime on the launch stream, so they also fire inside replayed launch lists.
 
 
 def _drop(d: Drop):
@@ -87,14 +86,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
     lib = L.load()
     d = _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
                    n_valid, k_valid, m_valid)
-    tap = event_taps.get(tag) if tag is not None and event_taps else None
-    if tap is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    timed = _taps_on and tag in TAPS
+    if timed:
+        tap(tag, 0)
     L.check(lib.vct_gemm(d, L.stream_ptr()), "vct_gemm")
-    if tap is not None:
-        e1.record()
-        tap.append((e0, e1))
+    if timed:
+        tap(tag, 1)
     return out
 
 
@@ -263,18 +260,21 @@ def advance_seed(seed):
     L.check(L.load().vct_advance_seed(seed.data_ptr(), L.stream_ptr()), "vct_advance_seed")
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step_dev, skip=(0, 0), bump=True):
+def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step_dev, skip=(0, 0), bump=True,
+              hyper=None):
     """Fused Adam/AdamW over flat fp32 buffers (+ bf16 shadow refresh).  step_dev: int32[1] device counter.
     `param` may be a slice of the flat buffer (range-by-range stepping): pass the same slice of every buffer,
-    `skip` relative to the slice start, bump=False, and finish with adam_bump(step_dev)."""
+    `skip` relative to the slice start, bump=False, and finish with adam_bump(step_dev).  hyper: device fp32 [5]
+    (lr, beta1, beta2, eps, weight_decay) read by the kernel instead of the scalars (graph / launch-list replays)."""
     L.check(L.load().vct_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
                                    param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                   step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.stream_ptr()), "vct_adam_step")
+                                   step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.ptr(hyper), L.stream_ptr()),
+            "vct_adam_step")
 
 
 def adam_bump(step_dev):
     L.check(L.load().vct_adam_step(step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), 0, 0,
-                                   0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, L.stream_ptr()), "vct_adam_step(bump)")
+                                   0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, 0, L.stream_ptr()), "vct_adam_step(bump)")
 
 
 def greedy_select(x, out, end_id: int, ended, ended_count, all_ended_at, t: int, cols=None):
@@ -293,3 +293,93 @@ def gather_pad_rows(store: torch.Tensor, offsets: torch.Tensor, idx: torch.Tenso
     L.check(L.load().vct_gather_pad_rows(L.dtype_code(out_dtype), B, tmax, E, store.data_ptr(), offsets.data_ptr(), idx.data_ptr(),
                                          out.data_ptr(), mask.data_ptr(), L.stream_ptr()), "vct_gather_pad_rows")
     return out, mask
+
+
+# ---- host runtime (csrc/vct_runtime.hip): cross-stream ordering, launch lists, live timing ----------------------------
+def _sptr(stream) -> int:
+    return stream.cuda_stream if stream is not None else L.stream_ptr()
+
+
+def stream_wait(waiter, signal):
+    """`waiter` (torch stream, None = current) waits for everything enqueued so far on `signal`.  Recordable."""
+    L.check(L.load().vct_stream_wait(_sptr(waiter), _sptr(signal)), "vct_stream_wait")
+
+
+def sync_record(ident: int, stream=None):
+    L.check(L.load().vct_sync_record(int(ident), _sptr(stream)), "vct_sync_record")
+
+
+def sync_wait(ident: int, stream=None):
+    L.check(L.load().vct_sync_wait(int(ident), _sptr(stream)), "vct_sync_wait")
+
+
+TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6}
+_taps_on = False
+
+
+def taps_enable(on: bool):
+    global _taps_on
+    _taps_on = bool(on)
+    L.check(L.load().vct_tap_enable(int(_taps_on)), "vct_tap_enable")
+
+
+def tap(tag: str, phase: int, stream=None):
+    """Bracket a region of `stream` with HIP timing events (phase 0 = start, 1 = end); no-op while taps are disabled."""
+    if _taps_on:
+        L.check(L.load().vct_tap(TAPS[tag], phase, _sptr(stream)), "vct_tap")
+
+
+def tap_collect(tag: str, cap: int = 4096):
+    """Elapsed milliseconds of every bracket of `tag` executed since the last collect (waits for them)."""
+    buf = (L.f32 * cap)()
+    n = L.load().vct_tap_collect(TAPS[tag], buf, cap)
+    if n < 0:
+        L.check(n, "vct_tap_collect")
+    return [float(buf[i]) for i in range(n)]
+
+
+class LaunchList:
+    """One recorded step: `with ll.record(): <issue the step>` captures every vct_* launch made on this thread (nothing
+    executes), `ll.replay()` re-issues them from C.  Launches aimed at the stream that was current at record time go to
+    the stream current at replay time."""
+
+    def __init__(self):
+        h = L.vp()
+        L.check(L.load().vct_cmdlist_create(L.C.byref(h)), "vct_cmdlist_create")
+        self._h = h
+
+    class _Rec:
+        def __init__(self, ll):
+            self.ll = ll
+
+        def __enter__(self):
+            L.check(L.load().vct_cmdlist_begin(self.ll._h, L.stream_ptr()), "vct_cmdlist_begin")
+            return self.ll
+
+        def __exit__(self, *exc):
+            L.check(L.load().vct_cmdlist_end(self.ll._h), "vct_cmdlist_end")
+            return False
+
+    def record(self):
+        return LaunchList._Rec(self)
+
+    def replay(self):
+        L.check(L.load().vct_cmdlist_replay(self._h, L.stream_ptr()), "vct_cmdlist_replay")
+
+    def __len__(self):
+        return int(L.load().vct_cmdlist_size(self._h))
+
+    @property
+    def n_streams(self):
+        return int(L.load().vct_cmdlist_streams(self._h))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            L.load().vct_cmdlist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -88,28 +88,47 @@ class FusedAdam(torch.optim.Optimizer):
         emb = "cap_decoder.tgt_to_emb.weight"
         a = ps.offsets[emb]
         self.skip = (a, a + (ps.params[emb].numel() + ps.ALIGN - 1) // ps.ALIGN * ps.ALIGN)
+        # the reference builds its optimizer over filter(requires_grad) (train.py:24): parameters outside the caption
+        # path (matching.*: frozen by mode('caption'), never given a gradient here) are neither stepped nor decayed
+        self.end = model.caption_param_end
+        # lr / betas / eps / weight decay live in DEVICE memory (read by the kernel): a captured hipGraph or a recorded
+        # launch list follows LR schedulers and load_state_dict instead of freezing the values of the recording step
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=ps.flat.device)
+        self._hyper_host = None
+        self.sync_hyper()
+
+    def _hyper_now(self):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+
+    def sync_hyper(self):
+        """Upload the hyper-parameters if a scheduler / user changed them (host check, rare H2D copy).  Called by
+        CaptionTrainer.step before every step, outside any capture."""
+        h = self._hyper_now()
+        if h != self._hyper_host:
+            self.hyper[:5].copy_(torch.tensor(h, dtype=torch.float32))
+            self._hyper_host = h
 
     @torch.no_grad()
     def step(self, closure=None):
-        g = self.param_groups[0]
-        ps = self.model._ps
-        shadow = ps.cflat if ps.compute_dtype != torch.float32 else None
-        ops.adam_step(ps.flat, ps.gflat, self.exp_avg, self.exp_avg_sq, shadow, g["lr"], g["betas"][0], g["betas"][1],
-                      g["eps"], g["weight_decay"], self.step_dev, self.skip)
-        ps._stamp = sum(p._version for p in ps.params.values())   # shadow is current
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        self.step_range(0, self.end)
+        self.finish_ranges()
 
     @torch.no_grad()
     def step_range(self, a: int, b: int):
         """Adam on flat elements [a, b) only, without advancing the step counter (range-by-range stepping as
         gradient buckets complete); call finish_ranges() after the last range of the step."""
+        b = min(b, self.end)
         if b <= a:
             return
-        g = self.param_groups[0]
+        lr, b1, b2, eps, wd = self._hyper_now()
         ps = self.model._ps
         shadow = ps.cflat[a:b] if ps.compute_dtype != torch.float32 else None
         s0, s1 = max(self.skip[0], a) - a, min(self.skip[1], b) - a
-        ops.adam_step(ps.flat[a:b], ps.gflat[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], shadow, g["lr"], g["betas"][0],
-                      g["betas"][1], g["eps"], g["weight_decay"], self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False)
+        ops.adam_step(ps.flat[a:b], ps.gflat[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], shadow, lr, b1, b2, eps, wd,
+                      self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper)
 
     @torch.no_grad()
     def finish_ranges(self):
@@ -118,7 +137,7 @@ class FusedAdam(torch.optim.Optimizer):
         ps._stamp = sum(p._version for p in ps.params.values())
 
     def zero_grad(self, set_to_none: bool = True):
-        pass   # the backward schedule overwrites every gradient
+        pass   # the backward schedule OVERWRITES every gradient (no accumulation across backward calls on the fast path)
 
     # ---- checkpointing (checkpoint.save_training_state): moments and step live outside torch's per-param state ----
     def state_dict(self):
@@ -141,6 +160,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg.copy_(fused["exp_avg"])
         self.exp_avg_sq.copy_(fused["exp_avg_sq"])
         self.step_dev.fill_(fused["step"])
+        self.sync_hyper()
 
 
 def build_optimizer(train_cfg: dict, model):
@@ -177,16 +197,26 @@ class CaptionTrainer:
     """One object = the reference's `model(...) -> zero_grad -> backward -> step` loop body
     (train.py:123-126) on the kernel fast path, with the gradient exchange folded into backward.
 
-    use_graph=True (single-GPU, FusedAdam): the whole step -- forward, backward, Adam, dropout-seed
-    advance, ~190 kernel launches -- is captured once per input shape into a hipGraph and replayed;
-    inputs are copied into static buffers, the dropout seed and the Adam step counter live in device
-    memory so every replay sees fresh values."""
+    Executors of the ~100-launch step (single GPU, FusedAdam):
+      * eager (default off the GPU fast path): Python issues every launch through ctypes;
+      * launch_list=True: the step is recorded ONCE per input shape into a C-side launch list (ops.LaunchList:
+        every launch with its stream, every cross-stream edge) and re-issued by one C call per step -- eager
+        two-stream semantics without the Python/ctypes cost per launch;
+      * use_graph=True: the step is captured into a hipGraph (bitwise equal, but replay serialises the two streams).
+    Inputs are copied into static buffers; the dropout seed, the Adam step counter and the Adam hyper-parameters live
+    in device memory, so every replay sees fresh values.  Recordings are dropped when an activation buffer had to grow
+    (engine._Buf.generation), because they bake device pointers."""
 
-    def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None, use_graph: bool = False):
+    def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None, use_graph: bool = False,
+                 launch_list: Optional[bool] = None):
         self.model, self.opt, self.ex = model, optimizer, exchange
         model._unit_loss_grad = True
-        self.use_graph = bool(use_graph) and (exchange is None or not exchange.active) and isinstance(optimizer, FusedAdam)
+        single = (exchange is None or not exchange.active) and isinstance(optimizer, FusedAdam)
+        self.use_graph = bool(use_graph) and single
+        self.use_list = (bool(launch_list) if launch_list is not None else False) and single and not self.use_graph
         self._graphs = {}
+        self._lists = {}
+        self._gen = None
         # single GPU: per-bucket Adam on the side stream was measured SLOWER (3.28 vs 3.14 ms/step: the 6.5 TB/s
         # optimizer pass steals HBM bandwidth from the GEMMs it overlaps), so it is opt-in; with a gradient exchange
         # Adam always runs per bucket as each all-reduce lands (it overlaps the wire, not the GEMMs)
@@ -195,6 +225,7 @@ class CaptionTrainer:
     def _step_kernels(self, feats, mask, ids):
         m = self.model
         fused = isinstance(self.opt, FusedAdam)
+        ops.tap("step", 0)
         if not fused:
             m._ps.refresh_shadow(force=True)      # a torch optimizer wrote the fp32 masters: re-cast the shadow
             m._ps._stamp = sum(p._version for p in m._ps.params.values())
@@ -220,19 +251,25 @@ class CaptionTrainer:
                 if side is None:
                     self.opt.step_range(*buckets[i])
                     return
-                side.wait_stream(torch.cuda.current_stream())
+                ops.stream_wait(side, None)
                 with torch.cuda.stream(side):
                     self.opt.step_range(*buckets[i])
             loss = m.train_step_kernels(feats, mask, ids, bucket_ready=hook)   # zero_grad is implicit: grads are overwritten
             if _StackBase._side is not None:
-                torch.cuda.current_stream().wait_stream(_StackBase._side)
+                ops.stream_wait(None, _StackBase._side)
             self.opt.finish_ranges()
         elif fused and feats.is_cuda and m.overlap_enc_bwd:
             # the encoder backward is still running on the side stream when the decoder's tail is done: Adam on everything
             # but the encoder (86 % of the parameters at cfg-B) fills that gap on the main stream, the rest follows the join
             loss = m.train_step_kernels(feats, mask, ids, defer_join=True)
             a = m.encoder_param_begin
+            # the decoder layers' weight gradients and the d(memory) GEMMs were issued on the SIDE stream: Adam reads
+            # those gradients and rewrites the weights those kernels read, so the main stream joins the side stream first
+            # (it is idle here: the encoder backward has not been enqueued yet)
+            m.cap_decoder._engine().join_side()
+            ops.tap("adam", 0)
             self.opt.step_range(0, a)            # enqueued BEFORE the encoder backward: one launch vs ~35
+            ops.tap("adam", 1)
             m.launch_encoder_backward()
             m.join_backward()
             self.opt.step_range(a, m._ps.total)
@@ -242,19 +279,60 @@ class CaptionTrainer:
             self.opt.step()
         if m.training and m.video_encoder.cfg["dropout"] > 0:
             ops.advance_seed(m._seed)
+        ops.tap("step", 1)
         return loss
+
+    def _static_inputs(self, key, feats, mask, ids):
+        st = getattr(self, "_static", None)
+        if st is None:
+            st = self._static = {}
+        s = st.get(key)
+        if s is None:
+            s = st[key] = (feats.clone(), None if mask is None else mask.clone(), ids.clone())
+        else:
+            s[0].copy_(feats, non_blocking=True)
+            if mask is not None:
+                s[1].copy_(mask, non_blocking=True)
+            s[2].copy_(ids, non_blocking=True)
+        return s
 
     def step(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
         """Returns this rank's loss as a device tensor [1] (no host sync)."""
-        if not self.use_graph:
+        if isinstance(self.opt, FusedAdam):
+            self.opt.sync_hyper()
+        if not (self.use_graph or self.use_list):
             return self._step_kernels(feats, mask, ids)
-        key = (tuple(feats.shape), None if mask is None else tuple(mask.shape), tuple(ids.shape), self.model.training)
+        from .engine import _Buf
+        if self._gen != _Buf.generation:          # a buffer grew since the recordings were made: they bake stale pointers
+            self._graphs.clear()
+            self._lists.clear()
+            self._gen = _Buf.generation
+        key = (tuple(feats.shape), feats.dtype, None if mask is None else tuple(mask.shape), tuple(ids.shape), self.model.training)
+        static = self._static_inputs(key, feats, mask, ids)
+        if self.use_list:
+            ll = self._lists.get(key)
+            if ll is None:
+                # first step of this shape: run it eagerly on the static copies (allocates every buffer), then record the
+                # same schedule (recording executes nothing); later calls replay the recording
+                eager_loss = self._step_kernels(*static).clone()
+                if self._gen != _Buf.generation:      # the eager step allocated: older recordings are stale, this one is not made yet
+                    self._graphs.clear()
+                    self._lists.clear()
+                    self._gen = _Buf.generation
+                ll = ops.LaunchList()
+                with ll.record():
+                    loss = self._step_kernels(*static)
+                self._lists[key] = (ll, loss)
+                return eager_loss
+            ll[0].replay()
+            return ll[1]
         g = self._graphs.get(key)
         if g is None:
-            # first step of this shape: run it eagerly on static copies (allocates every buffer), then record
-            # the same schedule (stream capture executes nothing); later calls replay the recording
-            static = (feats.clone(), None if mask is None else mask.clone(), ids.clone())
             eager_loss = self._step_kernels(*static).clone()
+            if self._gen != _Buf.generation:
+                self._graphs.clear()
+                self._lists.clear()
+                self._gen = _Buf.generation
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
@@ -263,13 +341,9 @@ class CaptionTrainer:
             except Exception:                       # capture is an optimisation, never a requirement
                 self.use_graph = False
                 return eager_loss
-            self._graphs[key] = (graph, static, loss)
+            self._graphs[key] = (graph, loss)
             return eager_loss
-        graph, static, loss = g
-        static[0].copy_(feats, non_blocking=True)
-        if mask is not None:
-            static[1].copy_(mask, non_blocking=True)
-        static[2].copy_(ids, non_blocking=True)
+        graph, loss = g
         graph.replay()
         return loss
 
