@@ -133,6 +133,36 @@ int vct_attn_fwd(const vct_attn_desc* d, void* stream);
 int vct_attn_bwd(const vct_attn_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused attention block forward (bf16): y = LayerNorm(res + dropout(attn_core(q,k,v) W_out^T + b_out)), ONE launch,
+ * one workgroup per batch element, one wave per head; the attention output goes from registers through LDS into the
+ * output projection (W_out streamed from L2 straight into MFMA B fragments), bias / dropout / residual / LayerNorm in
+ * the epilogue (csrc/vct_attn_block.hip).
+ * replaces: the SDPA core + out_proj nn.Linear + dropout + residual add + nn.LayerNorm of every attention block of
+ * nn.TransformerEncoderLayer / nn.TransformerDecoderLayer (torch nn/modules/transformer.py:951-957,1143-1167; built at
+ * MMEncoder.py:236-238, CapDecoder.py:18-20) -- i.e. vct_attn_fwd + vct_gemm + vct_add_ln_fwd of the unfused path.
+ *   attn: as vct_attn_fwd (attn.o = attention output [B*Lq, H*hd], saved for the out_proj weight gradient; attn.seed /
+ *   p_drop / site = dropout on the attention probabilities; batch strides must be 0).
+ *   w_out bf16 [d, d] (nn.Linear layout [out, in]), b_out fp32 [d], res bf16 [B*Lq, d], gamma / beta fp32 [d].
+ *   a_out bf16: out_proj output BEFORE dropout (what vct_add_ln_bwd re-reads as `x`), y bf16, mean / rstd fp32 [B*Lq].
+ *   site_res: dropout site of the residual dropout (seed and p of attn).  d = H*hd.
+ * The saved tensors and dropout streams equal the unfused kernels', so the unfused backward kernels run behind it.
+ * vct_attn_block_supported: 1 when the shape is covered (bf16; H=8,hd=64 or H=4,hd in {16,32}; Lq <= 32; LDS budget).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_attn_block_desc {
+  vct_attn_desc attn;
+  const void* w_out; int64_t ldw;
+  const float* b_out;
+  const void* res; int64_t ld_res;
+  const float* gamma; const float* beta;
+  void* a_out; int64_t ld_a;
+  void* y; int64_t ld_y;
+  float* mean; float* rstd;
+  uint32_t site_res; int32_t reserved;
+} vct_attn_block_desc;
+int vct_attn_block_supported(int dtype, int H, int hd, int Lq, int Lk);
+int vct_attn_block_fwd(const vct_attn_block_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).
  * replaces: dropoutN + residual add + nn.LayerNorm (torch nn/modules/transformer.py:951-957,
  * 1143-1153) and the stack-final norms (MMEncoder.py:238, CapDecoder.py:20).
@@ -266,6 +296,12 @@ int vct_stream_wait(void* waiter_stream, void* signal_stream);
  * stream waits for the most recent mark with that id. */
 int vct_sync_record(int id, void* stream);
 int vct_sync_wait(int id, void* stream);
+/* A stream whose kernels may only run on the compute units set in cu_mask (bit i of word i/32 = CU i; `words` 32-bit
+ * words; words == 0: an ordinary non-blocking stream).  MI355X has 256 CUs in 8 XCDs; a throughput-bound kernel (the
+ * vocabulary weight gradient, Adam) confined to a subset of the CUs runs BESIDE a latency-bound chain of small kernels
+ * confined to the complement instead of starving it (hipExtStreamCreateWithCUMask).  The caller owns the stream. */
+int vct_stream_create_masked(const uint32_t* cu_mask, int words, void** out_stream);
+int vct_stream_destroy(void* stream);
 /* Live kernel timing with HIP events on the launch stream (bench.py's roofline block): vct_tap(tag, 0, s) / vct_tap(tag,
  * 1, s) bracket a region of stream s; every bracket executed (eagerly or by a replay) while taps are enabled adds one
  * (start, end) pair to tag's pool.  vct_tap_collect waits for the pairs, writes their elapsed milliseconds

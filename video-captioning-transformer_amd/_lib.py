@@ -7,6 +7,7 @@ import torch  # must be imported first: libvct_hip.so binds to the HIP runtime t
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
+_AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
 ABI_VERSION = 3
@@ -36,6 +37,12 @@ class AttnDesc(C.Structure):
                 ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64)]
 
 
+class AttnBlockDesc(C.Structure):
+    _fields_ = [("attn", AttnDesc), ("w_out", vp), ("ldw", i64), ("b_out", vp), ("res", vp), ("ld_res", i64),
+                ("gamma", vp), ("beta", vp), ("a_out", vp), ("ld_a", i64), ("y", vp), ("ld_y", i64),
+                ("mean", vp), ("rstd", vp), ("site_res", u32), ("reserved", i32)]
+
+
 _SIGS = {
     "vct_abi_version": (C.c_int, []),
     "vct_build_info": (C.c_int, [C.c_char_p, C.c_int]),
@@ -45,6 +52,8 @@ _SIGS = {
     "vct_gemm_grouped_workspace_bytes": (i64, [C.POINTER(GemmDesc), i32, i32]),
     "vct_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "vct_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vct_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_ln_ws_rows": (C.c_int, [C.c_int]),
@@ -70,6 +79,8 @@ _SIGS = {
     "vct_stream_wait": (C.c_int, [vp, vp]),
     "vct_sync_record": (C.c_int, [C.c_int, vp]),
     "vct_sync_wait": (C.c_int, [C.c_int, vp]),
+    "vct_stream_create_masked": (C.c_int, [C.POINTER(u32), C.c_int, C.POINTER(vp)]),
+    "vct_stream_destroy": (C.c_int, [vp]),
     "vct_tap_enable": (C.c_int, [C.c_int]),
     "vct_tap": (C.c_int, [C.c_int, C.c_int, vp]),
     "vct_tap_collect": (C.c_int, [C.c_int, C.POINTER(f32), C.c_int]),
@@ -88,6 +99,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if _AB_LIB:
+        lib = C.CDLL(_AB_LIB)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
     _ensure_current()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(

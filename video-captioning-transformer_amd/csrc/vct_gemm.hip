@@ -432,6 +432,11 @@ static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
   p.partial = nullptr; p.bias_partial = nullptr; p.counters = nullptr;
   p.waves8 = pl.waves8;
   p.split = pl.split;
+  {
+    static const char* env = getenv("VCT_GEMM_NT");          // A/B switch: 0 = never, 1 = always
+    const size_t out_bytes = (size_t)d->M * (size_t)d->N * (d->out_dtype == VCT_BF16 ? 2 : 4);
+    p.nt_store = env != nullptr ? (env[0] == '1') : (out_bytes > ((size_t)64 << 20));
+  }
   if (pl.split > 1) {
     if (use_counters(d, pl)) p.counters = d->tile_counters;
     p.partial = reinterpret_cast<float*>(d->workspace);

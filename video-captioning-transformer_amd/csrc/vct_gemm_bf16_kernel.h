@@ -115,6 +115,13 @@ __device__ __forceinline__ float coherent_load1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <bool MC, int R, bool KSPLIT>
 __device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, int ks, int lane) {
   const int i = lane & 15, g = lane >> 4;
@@ -139,9 +146,6 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   constexpr int NW = WGM * WGN, NT = 64 * NW;         // waves / threads per workgroup
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
-  constexpr int STG_STRIDE = WN + 4;
-  constexpr int STG_BYTES = NW * 16 * STG_STRIDE * 4;
-  static_assert(NBUF * BUF_BYTES >= STG_BYTES, "staging must fit");
   __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[NBUF * BUF_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -283,12 +287,56 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       }
   }
   __syncthreads();
-  float* stg = reinterpret_cast<float*>(lds_raw) + wave * 16 * STG_STRIDE;
-  const bool part = p.partial != nullptr;
+  // The tile leaves through WORKGROUP-wide row slabs: for each 16-row MFMA tile row i every wave drops its 16 x WN piece
+  // into a shared fp32 slab [WGM*16 rows][BN], then every lane picks up ONE 16-byte output chunk such that a row of the
+  // slab is written by consecutive lanes -- a store instruction covers whole BN*sizeof(TO)-byte row segments (>= 128 B:
+  // full cache lines).  The former per-wave transpose stored 16 rows x WN*sizeof(TO) = 64-byte HALF lines per instruction
+  // (WN = 32 bf16), which the L2 had to merge: a second 20 MB output (the saved pre-activation) cost 12.5 us = 1.6 TB/s.
+  float* stage_base = reinterpret_cast<float*>(lds_raw);
   constexpr int VO = 16 / (int)sizeof(TO);
-  constexpr int CPR = WN / VO;
-  constexpr int CPL = (16 * CPR + 63) / 64;
-  constexpr bool CPL_PARTIAL = (16 * CPR) < 64;   // fewer chunks than lanes (narrow wave tile)
+  // two ways out, chosen per tile shape (measured on the same box: the slab form takes the FFN GEMM with activation +
+  // saved pre-activation from 42 to 38 us, the per-wave form keeps the 128x128 vocabulary projection at 250 instead of 273 us):
+  //   SLAB   every wave drops its 16 x WN piece of tile row i into a workgroup-wide fp32 slab [WGM*16][BN]; after a
+  //          barrier each lane owns ONE 16-byte chunk such that consecutive lanes cover a whole output row of the tile
+  //          (BN*sizeof(TO) >= 128 B: full cache lines per store instruction);
+  //   !SLAB  every wave transposes through its private 16 x WN slab (no barrier; 16 rows x WN*sizeof(TO) per instruction).
+  constexpr bool SLAB = (BM * BN != 128 * 128);
+  constexpr int SLAB_ROWS = WGM * 16, CPRW = BN / VO;
+  constexpr int CPRV = WN / VO;                                        // per-wave form: chunks per staged row
+  constexpr int SSTR = SLAB ? BN + 4 : WN + 4;
+  constexpr int STAGE_FLOATS = SLAB ? SLAB_ROWS * SSTR : NW * 16 * SSTR;
+  constexpr int NSLAB = (SLAB && 2 * STAGE_FLOATS * 4 <= NBUF * BUF_BYTES) ? 2 : 1;
+  static_assert(STAGE_FLOATS * 4 <= NBUF * BUF_BYTES, "epilogue staging must fit in the operand buffers");
+  static_assert(!SLAB || (SLAB_ROWS * CPRW) % NT == 0, "slab chunks must divide over the workgroup");
+  constexpr int CPL = SLAB ? SLAB_ROWS * CPRW / NT : (16 * CPRV + 63) / 64;
+  const bool part = p.partial != nullptr;
+  // this lane's chunk(s): staging offset e_lds (floats), row offset inside the tile (without i*16) e_row, tile column e_col
+  int e_lds[CPL], e_row[CPL], e_col[CPL];
+  bool e_act[CPL];
+  float bvec[CPL][VO];
+#pragma unroll
+  for (int c = 0; c < CPL; c++) {
+    if constexpr (SLAB) {
+      const int chunk = c * NT + tid;
+      const int sr = chunk / CPRW, sc = (chunk % CPRW) * VO;
+      e_lds[c] = sr * SSTR + sc; e_row[c] = (sr >> 4) * WM + (sr & 15); e_col[c] = sc; e_act[c] = true;
+    } else {
+      const int chunk = c * 64 + lane;
+      const int rr = (chunk / CPRV) & 15, cc = (chunk % CPRV) * VO;
+      e_lds[c] = wave * 16 * SSTR + rr * SSTR + cc; e_row[c] = wm * WM + rr; e_col[c] = wn * WN + cc;
+      e_act[c] = chunk < 16 * CPRV;
+    }
+#pragma unroll
+    for (int q = 0; q < VO; q++) bvec[c][q] = 0.0f;
+  }
+  if (p.bias != nullptr && (!part || p.counters != nullptr)) {   // split-K: the in-kernel reduce applies the epilogue
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+#pragma unroll
+      for (int q = 0; q < VO; q++) bvec[c][q] = p.bias[min(n0 + e_col[c] + q, p.N - 1)];
+    }
+  }
+
   const Dropout dr = make_dropout(p.seed, p.site, p.p_drop);
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* preact = reinterpret_cast<TO*>(p.preact);
@@ -297,21 +345,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   float* partC = part ? p.partial + (size_t)zid * (size_t)p.M * (size_t)p.N : nullptr;
   const long ldo = part ? (long)p.N : p.ldc;
   const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
-  const bool lane_active = !CPL_PARTIAL || lane < 16 * CPR;
-  const bool nt_store = (size_t)p.M * (size_t)p.N * sizeof(TO) > ((size_t)64 << 20);
-  float bvec[CPL][VO];
-#pragma unroll
-  for (int c = 0; c < CPL; c++)
-#pragma unroll
-    for (int q = 0; q < VO; q++) bvec[c][q] = 0.0f;
-  if (p.bias != nullptr && (!part || p.counters != nullptr)) {   // split-K: the in-kernel reduce applies the epilogue
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int col = n0 + wn * WN + ((c * 64 + lane) % CPR) * VO;
-#pragma unroll
-      for (int q = 0; q < VO; q++) bvec[c][q] = p.bias[min(col + q, p.N - 1)];
-    }
-  }
+  const bool nt_store = p.nt_store != 0;
   struct alignas(16) OutV { TO e[VO]; };
   // bias / activation (+ saved pre-activation) / activation derivative / dropout / residual-gradient accumulate on
   // VO consecutive columns of one row, then the store -- shared by the direct path and the in-kernel split-K reduce
@@ -325,8 +359,8 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       for (int q = 0; q < VO; q++) {
         float x = v[q] + bv[q];
         pv.e[q] = from_f<TO>(x);
-        x = act_f(p.act, x);
-        if (has_d) x *= dact_f(p.dact_kind, to_f<TO>(dv.e[q]));
+        x = act_fast_f(p.act, x);
+        if (has_d) x *= dact_fast_f(p.dact_kind, to_f<TO>(dv.e[q]));
         x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
         if (has_a) x += to_f<TO>(av.e[q]);
         ov.e[q] = from_f<TO>(x);
@@ -347,8 +381,8 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         if (col + q >= p.N) break;
         float x = v[q] + bv[q];
         if (preact != nullptr) preact[(size_t)row * p.ld_preact + col + q] = from_f<TO>(x);
-        x = act_f(p.act, x);
-        if (dact != nullptr) x *= dact_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
+        x = act_fast_f(p.act, x);
+        if (dact != nullptr) x *= dact_fast_f(p.dact_kind, to_f<TO>(dact[(size_t)row * p.ld_dact + col + q]));
         x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
         if (addend != nullptr) x += to_f<TO>(addend[(size_t)row * p.ld_addend + col + q]);
         C[(size_t)row * p.ldc + col + q] = from_f<TO>(x);
@@ -357,23 +391,28 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   };
   static_for<TM>([&](auto I) {
     constexpr int i = decltype(I)::value;
+    float* stage = stage_base + (NSLAB == 2 ? (i & 1) * STAGE_FLOATS : 0);
+    if constexpr (SLAB && NSLAB == 1 && i > 0) lds_barrier();    // the previous slab has been read by everyone
     static_for<TN>([&](auto J) {
       constexpr int j = decltype(J)::value;
 #pragma unroll
-      for (int r = 0; r < 4; r++) stg[(g4 + r) * STG_STRIDE + j * 16 + c16] = acc[i][j][r];
+      for (int r = 0; r < 4; r++) {
+        if constexpr (SLAB) stage[(wm * 16 + g4 + r) * SSTR + wn * WN + j * 16 + c16] = acc[i][j][r];
+        else stage[wave * 16 * SSTR + (g4 + r) * SSTR + j * 16 + c16] = acc[i][j][r];
+      }
     });
+    if constexpr (SLAB) lds_barrier();
     static_for<CPL>([&](auto CI) {
       constexpr int c = decltype(CI)::value;
-      const int chunk = c * 64 + lane;
-      const int rr = (chunk / CPR) & 15, cc = (chunk % CPR) * VO;
-      const int row = m0 + wm * WM + i * 16 + rr, col = n0 + wn * WN + cc;
+      const int row = m0 + e_row[c] + i * 16, col = n0 + e_col[c];
       float v[VO];
 #pragma unroll
       for (int q = 0; q < VO; q += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(stg + rr * STG_STRIDE + cc + q);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + e_lds[c] + q);
         v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
       }
-      if (!lane_active || row >= p.M || col >= p.N) return;
+      if (!e_act[c]) return;
+      if (row >= p.M || col >= p.N) return;
       const bool full = vec_ok && (col + VO <= p.N);
       if (part) {
         float* dst = partC + (size_t)row * p.N + col;
@@ -412,10 +451,8 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       constexpr int i = decltype(I)::value;
       static_for<CPL>([&](auto CI) {
         constexpr int c = decltype(CI)::value;
-        const int chunk = c * 64 + lane;
-        const int rr = (chunk / CPR) & 15, cc = (chunk % CPR) * VO;
-        const int row = m0 + wm * WM + i * 16 + rr, col = n0 + wn * WN + cc;
-        if (!lane_active || row >= p.M || col >= p.N) return;
+        const int row = m0 + e_row[c] + i * 16, col = n0 + e_col[c];
+        if (!e_act[c] || row >= p.M || col >= p.N) return;
         const float* src = p.partial + (size_t)row * p.N + col;
         const bool full = vec_ok && (col + VO <= p.N) && (p.ldc % VO == 0) && (((uintptr_t)p.C & 15) == 0);
         float s[VO];

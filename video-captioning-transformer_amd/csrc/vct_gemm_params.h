@@ -24,6 +24,7 @@ struct GemmP {
   int waves8;           // 128x128 tile with 8 waves (2x4) instead of 4 (2x2)
   int split;            // number of K splits (gridDim.z of the single launch)
   int* counters;        // != nullptr: per-tile arrival counters (zero on entry/exit): single-pass split-K
+  int nt_store;         // streaming-size output: non-temporal stores (keeps the operand tiles L2-resident)
 };
 
 struct GemmGroupP {

@@ -187,6 +187,22 @@ extern "C" int vct_stream_wait(void* waiter, void* signal) {
   return do_wait(id, (hipStream_t)waiter);
 }
 
+// ---- CU-masked streams ------------------------------------------------------------------------------------------------
+extern "C" int vct_stream_create_masked(const uint32_t* cu_mask, int words, void** out_stream) {
+  if (out_stream == nullptr || (words > 0 && cu_mask == nullptr) || words < 0) return VCT_E_ARG;
+  hipStream_t s = nullptr;
+  hipError_t e = words == 0 ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking)
+                            : hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask);
+  if (e != hipSuccess) return (int)e;
+  *out_stream = (void*)s;
+  return VCT_OK;
+}
+extern "C" int vct_stream_destroy(void* stream) {
+  if (stream == nullptr) return VCT_E_ARG;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? VCT_OK : (int)e;
+}
+
 extern "C" int vct_tap_enable(int on) { g_tap_on = on != 0; return VCT_OK; }
 extern "C" int vct_tap(int tag, int phase, void* stream) {
   if (tag < 0 || tag >= N_TAGS || (phase != 0 && phase != 1)) return VCT_E_ARG;

@@ -248,6 +248,39 @@ class _StackBase:
         ops.gemm(o, self.W(lp + "out_proj.weight"), a, bias=self.F(lp + "out_proj.bias"))
         return a
 
+    # attention core + out_proj + dropout + residual + LayerNorm in ONE launch (vct_attn_block_fwd).  Measured at cfg-B
+    # (tools/attn_block_bench.py): 31.9 us fused vs 28.1 us for the three kernels -- its phases are additive (launch +
+    # epilogue 12.1, attention 8.5, projection 11.3 us) because one 8-wave workgroup per CU leaves nothing to overlap them
+    # with, so the unfused kernels stay the default; the fused block is kept (tested) for larger per-CU concurrency.
+    fuse_attn_block = False
+
+    def _attn_ln_fwd(self, b, tag, ntag, lp, np_, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, site_ln, self_attn=True):
+        """y = LayerNorm(x + dropout(out_proj(MHA(x, kv_src)))) of one attention block; saves o, a, mean, rstd for the
+        backward.  One fused launch behind the q/k/v projection GEMM(s) when the shape is covered
+        (ops.attn_block_supported), else attention core + out_proj GEMM + add-LayerNorm kernels."""
+        d, H = self.cfg["d"], self.cfg["nhead"]
+        if not (self.fuse_attn_block and ops.attn_block_supported(self.dt, H, d // H, Lq, Lk)):
+            a = self._attn_block_fwd(b, tag, lp, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn=self_attn)
+            return self._ln_fwd(b, ntag, np_, a, x, site_ln)
+        Mq = x.shape[0]
+        if self_attn:
+            qkv = b.get(tag + "qkv", (Mq, 3 * d), self.dt)
+            ops.gemm(x, self.W(lp + "in_proj_weight"), qkv, bias=self.F(lp + "in_proj_bias"))
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            q = b.get(tag + "q", (Mq, d), self.dt)
+            ops.gemm(x, self.W(lp + "in_proj_weight")[:d], q, bias=self.F(lp + "in_proj_bias")[:d])
+            kv = self._cross_kv(b, tag, lp, kv_src)
+            k, v = kv[:, :d], kv[:, d:]
+        o = b.get(tag + "o", (Mq, d), self.dt)
+        a = b.get(tag + "a", (Mq, d), self.dt)
+        y = b.get(ntag + "y", (Mq, d), self.dt)
+        drop = self.drop(site)
+        return ops.attn_block_fwd(q, k, v, o, Bn, H, Lq, Lk, self.W(lp + "out_proj.weight"), self.F(lp + "out_proj.bias"), x,
+                                  self.F(np_ + "weight"), self.F(np_ + "bias"), a, y,
+                                  b.get(ntag + "mean", (Mq,), torch.float32), b.get(ntag + "rstd", (Mq,), torch.float32),
+                                  causal=causal, key_pad=key_pad, dropout=drop, site_res=site_ln)
+
     def _cross_kv(self, b, tag, lp, mem):
         """K/V projection of the encoder memory for one cross-attention block.  It depends on the memory only, so
         prefetch_cross_kv() issues it for every layer on the side stream at the start of the decoder stack, off the
@@ -406,8 +439,8 @@ class EncoderEngine(_StackBase):
         for l in range(L):
             lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
             b.t[tag + "x"] = x
-            a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, B, Te, Te, False, kpm, site + 1)
-            x1 = self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+            x1 = self._attn_ln_fwd(b, tag + "sa.", tag + "n1.", lp + "self_attn.", lp + "norm1.", x, x, B, Te, Te, False, kpm,
+                                   site + 1, site + 2)
             f = self._ffn_fwd(b, tag + "ff.", lp, x1, site + 3)
             x = self._ln_fwd(b, tag + "n2.", lp + "norm2.", f, x1, site + 4)
         b.t["x_last"] = x
@@ -457,8 +490,8 @@ class DecoderEngine(_StackBase):
         """x1 = LN1(x + drop(SelfMHA(x))) of decoder layer l."""
         lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
         b.t[tag + "x"] = x
-        a = self._attn_block_fwd(b, tag + "sa.", lp + "self_attn.", x, x, Bn, Sd, Sd, True, kpm, site + 1)
-        return self._ln_fwd(b, tag + "n1.", lp + "norm1.", a, x, site + 2)
+        return self._attn_ln_fwd(b, tag + "sa.", tag + "n1.", lp + "self_attn.", lp + "norm1.", x, x, Bn, Sd, Sd, True, kpm,
+                                 site + 1, site + 2)
 
     def forward_prefix(self, Bn: int, Te: int, ids: torch.Tensor, training: bool):
         """The part of the decoder forward that does not depend on the encoder memory -- token embedding and the bottom
@@ -498,8 +531,8 @@ class DecoderEngine(_StackBase):
                 x1 = x1_0
             else:
                 x1 = self._self_block(b, l, x, Bn, Sd, kpm)
-            c = self._attn_block_fwd(b, tag + "ca.", lp + "multihead_attn.", x1, mem, Bn, Sd, Te, False, None, site + 3, self_attn=False)
-            x2 = self._ln_fwd(b, tag + "n2.", lp + "norm2.", c, x1, site + 4)
+            x2 = self._attn_ln_fwd(b, tag + "ca.", tag + "n2.", lp + "multihead_attn.", lp + "norm2.", x1, mem, Bn, Sd, Te, False, None,
+                                   site + 3, site + 4, self_attn=False)
             f = self._ffn_fwd(b, tag + "ff.", lp, x2, site + 5)
             x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, site + 6)
         self._kv_prefetched = None

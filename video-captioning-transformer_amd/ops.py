@@ -159,6 +159,37 @@ def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop
     return o
 
 
+_ab_ok = {}
+
+
+def attn_block_supported(dtype, H, hd, Lq, Lk) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    key = (H, hd, Lq, Lk)
+    r = _ab_ok.get(key)
+    if r is None:
+        r = _ab_ok[key] = bool(L.load().vct_attn_block_supported(L.BF16, H, hd, Lq, Lk))
+    return r
+
+
+def attn_block_fwd(q, k, v, o, B, H, Lq, Lk, w_out, b_out, res, gamma, beta, a_out, y, mean, rstd, causal=False, key_pad=None,
+                   dropout: Drop = None, site_res: int = 0, flags: int = 0):
+    """Fused attention core + out_proj + dropout + residual + LayerNorm (include/vct_hip.h, vct_attn_block_fwd).
+    dropout = (seed, attention-probability site, p); site_res = site of the residual dropout."""
+    hd = o.shape[1] // H
+    bd = L.AttnBlockDesc()
+    a = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
+    a.o, a.ldo = o.data_ptr(), _ld(o)
+    bd.attn = a
+    bd.w_out, bd.ldw, bd.b_out = w_out.data_ptr(), _ld(w_out), b_out.data_ptr()
+    bd.res, bd.ld_res = res.data_ptr(), _ld(res)
+    bd.gamma, bd.beta = gamma.data_ptr(), beta.data_ptr()
+    bd.a_out, bd.ld_a, bd.y, bd.ld_y = a_out.data_ptr(), _ld(a_out), y.data_ptr(), _ld(y)
+    bd.mean, bd.rstd, bd.site_res, bd.reserved = mean.data_ptr(), rstd.data_ptr(), int(site_res), int(flags)
+    L.check(L.load().vct_attn_block_fwd(bd, L.stream_ptr()), "vct_attn_block_fwd")
+    return y
+
+
 def attn_bwd(q, k, v, d_o, dq, dk, dv, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
     hd = d_o.shape[1] // H
     d = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
@@ -311,6 +342,19 @@ def sync_record(ident: int, stream=None):
 
 def sync_wait(ident: int, stream=None):
     L.check(L.load().vct_sync_wait(int(ident), _sptr(stream)), "vct_sync_wait")
+
+
+def masked_stream(cu_bits, device=None):
+    """torch stream restricted to the compute units whose indices are in `cu_bits` (iterable of ints < 256); an empty /
+    None selection gives an ordinary stream.  Wraps vct_stream_create_masked; the stream lives as long as the process."""
+    words = (L.u32 * 8)()
+    n = 0
+    for c in (cu_bits or ()):
+        words[c // 32] |= (1 << (c % 32))
+        n += 1
+    h = L.vp()
+    L.check(L.load().vct_stream_create_masked(words, 8 if n else 0, L.C.byref(h)), "vct_stream_create_masked")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6}
