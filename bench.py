@@ -151,7 +151,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--payload", default="fp32", choices=["fp32", "bf16"], help="gradient all-reduce payload")
+    ap.add_argument("--payload", default="bf16", choices=["fp32", "bf16"], help="gradient reduce-scatter / all-reduce payload (N > 1)")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce", "c10d"],
+                    help="N > 1: reduce-scatter + Adam on the owned 1/N + all-gather over the library's RCCL communicator (default), "
+                         "all-reduce + replicated Adam over the same communicator, or torch.distributed's all-reduce (round-1 path)")
     ap.add_argument("--executor", default="list", choices=["list", "eager", "graph"],
                     help="N=1: how the ~100 launches of a step are issued -- a C-side recorded launch list (default), Python/ctypes "
                          "eager launches, or a captured hipGraph")
@@ -203,16 +206,45 @@ def main():
     if args.force_exchange and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    ex = (GradExchange(model, payload_dtype=torch.bfloat16 if args.payload == "bf16" else None, force=args.force_exchange)
-          if (world > 1 or args.force_exchange) else None)
     if args.torch_adam:
         flat = torch.nn.Parameter(model.flat_params); flat.grad = model.flat_grads
         opt = torch.optim.Adam([flat], lr=1e-4, betas=(0.9, 0.999), fused=True)
     else:
         opt, _ = build_optimizer(TRAIN_CFG, model)
+    ex, exchange_kind = None, None
+    if world > 1 or args.force_exchange:
+        payload = torch.bfloat16 if args.payload == "bf16" else None
+        if args.exchange != "c10d" and not args.torch_adam:
+            from vct_amd.comm import C10dColl, RcclColl
+            from vct_amd.trainer import ShardedExchange
+            coll, why = None, None
+            if os.environ.get("VCT_DIST_BACKEND", "nccl") == "nccl":
+                try:
+                    coll = RcclColl(device=device)
+                    ok = torch.tensor([1 if coll.self_test() else 0], device=device)
+                    if dist.is_initialized():
+                        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok) != 1:
+                        coll, why = None, "self-test of the collectives failed"
+                except Exception as e:      # never silently: say why the library's communicator is not carrying the gradients
+                    coll, why = None, repr(e)
+            else:
+                why = "VCT_DIST_BACKEND is not nccl"
+            if coll is None:
+                print(f"[bench] WARNING rank {rank}: vct_comm (own RCCL communicator) unavailable: {why}; using torch.distributed collectives",
+                      file=sys.stderr, flush=True)
+                coll = C10dColl()
+                payload = None
+            ex = ShardedExchange(model, opt, coll, sharded=args.exchange == "sharded", payload_dtype=payload)
+            exchange_kind = f"{args.exchange}/{'vct_comm' if coll.owns_stream else 'c10d'}"
+        else:
+            ex = GradExchange(model, payload_dtype=payload, force=args.force_exchange)
+            exchange_kind = "allreduce/torch.distributed"
     if args.graph:
         args.executor = "graph"
-    trainer = CaptionTrainer(model, opt, ex, use_graph=args.executor == "graph", launch_list=args.executor == "list")
+    # N > 1: eager launches unless asked otherwise (the recorded exchange is covered at world size 1 only: no multi-GPU box here)
+    use_list = args.executor == "list" and (world == 1 or os.environ.get("VCT_LIST_MULTI") == "1")
+    trainer = CaptionTrainer(model, opt, ex, use_graph=args.executor == "graph", launch_list=use_list)
     trainer.overlap_adam = args.overlap_adam
     feats, mask, ids = synthetic(args.batch, rank, device)
 
@@ -293,7 +325,7 @@ def main():
             "config": {"workload": "configs[1]: 2 enc + 2 dec layers d=512 ff=2048 H=8 V=30522, synthetic (256,12,512) "
                                    "features -> 20-token captions per GPU, fwd+bwd+Adam, dropout 0.3, SCE alpha 0.5",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S_TOK, "frames": T_FRAMES,
-                       "parallelism": f"dp{world}", "grad_allreduce_payload": args.payload if world > 1 else None,
+                       "parallelism": f"dp{world}", "grad_exchange": exchange_kind, "grad_payload": args.payload if ex is not None else None,
                        "executor": "eager" if not (trainer.use_list or trainer.use_graph) else ("list" if trainer.use_list else "graph")},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),

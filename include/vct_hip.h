@@ -296,6 +296,35 @@ int vct_stream_wait(void* waiter_stream, void* signal_stream);
  * stream waits for the most recent mark with that id. */
 int vct_sync_record(int id, void* stream);
 int vct_sync_wait(int id, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL / xGMI (csrc/vct_comm.hip).  One communicator per process (one process per GPU).
+ * replaces: DistributedDataParallel's bucketed NCCL all-reduce (train.py:217-219, utils.py:137-146).
+ *   vct_comm_unique_id: rank 0 fills 128 bytes; the caller ships them to every rank (any side channel).
+ *   vct_comm_init: collective over all ranks; the communicator owns a high-priority HIP stream for its collectives.
+ *   Collectives are IN PLACE on device buffers and asynchronous: enqueued on the communicator's stream, ordered behind
+ *   everything enqueued so far on after_stream when order_after != 0 (after_stream may be the NULL stream):
+ *     vct_comm_allreduce_avg       buf[0:count)              <- mean over ranks
+ *     vct_comm_reduce_scatter_avg  buf[r*n : (r+1)*n)        <- mean over ranks of that slice (n = count_per_rank, r = own rank)
+ *     vct_comm_all_gather          buf[q*n : (q+1)*n)        <- rank q's slice, for every q
+ *     vct_comm_broadcast           buf[0:count)              <- root's
+ *   dtype VCT_F32 | VCT_BF16.  vct_comm_wait(comm, s): stream s waits for everything issued on the communicator so far.
+ *   vct_comm_stream: the communicator's stream (to enqueue the optimizer of an owned shard between a reduce-scatter and
+ *   the all-gather of its result).  All of these are recordable into launch lists.
+ *   Return codes >= 10000 are ncclResult_t + 10000.  vct_comm_available() == 0: no RCCL could be bound at run time.
+ * --------------------------------------------------------------------------------------------- */
+int vct_comm_available(void);
+int vct_comm_unique_id(uint8_t* out128);
+int vct_comm_init(const uint8_t* id128, int rank, int world, void** out_comm);
+int vct_comm_destroy(void* comm);
+int vct_comm_rank(void* comm);
+int vct_comm_world(void* comm);
+int vct_comm_stream(void* comm, void** out_stream);
+int vct_comm_allreduce_avg(void* comm, void* buf, int64_t count, int dtype, void* after_stream, int order_after);
+int vct_comm_reduce_scatter_avg(void* comm, void* buf, int64_t count_per_rank, int dtype, void* after_stream, int order_after);
+int vct_comm_all_gather(void* comm, void* buf, int64_t count_per_rank, int dtype, void* after_stream, int order_after);
+int vct_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* after_stream, int order_after);
+int vct_comm_wait(void* comm, void* stream);
+
 /* A stream whose kernels may only run on the compute units set in cu_mask (bit i of word i/32 = CU i; `words` 32-bit
  * words; words == 0: an ordinary non-blocking stream).  MI355X has 256 CUs in 8 XCDs; a throughput-bound kernel (the
  * vocabulary weight gradient, Adam) confined to a subset of the CUs runs BESIDE a latency-bound chain of small kernels

@@ -33,7 +33,7 @@ def _batch(seed, dev):
     return feats, mask.to(dev), ids.to(dev)
 
 
-def _worker(rank, world, port, dtype_name, q):
+def _worker(rank, world, port, dtype_name, q, sharded=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -49,8 +49,14 @@ def _worker(rank, world, port, dtype_name, q):
     torch.manual_seed(50 + rank)                       # different init per rank: the constructor broadcast fixes it
     m = build_model(MC, VOCAB, "cuda", dtype)
     m.train()
-    ex = GradExchange(m)
     opt = FusedAdam(m, lr=1e-3)
+    if sharded:       # reduce-scatter -> Adam on the owned half -> all-gather (gloo carries the CUDA buffers on this one-GPU box)
+        from vct_amd.comm import C10dColl
+        from vct_amd.trainer import ShardedExchange
+        ex = ShardedExchange(m, opt, C10dColl())
+        assert ex.shard_of(0) is not None and ex.shard_of(0)[2] * world == ex.buckets[0][1] - ex.buckets[0][0]
+    else:
+        ex = GradExchange(m)
     tr = CaptionTrainer(m, opt, ex)
     start = m.flat_params.clone()
     losses = [float(tr.step(*_batch(10 + rank + 2 * k, dev))) for k in range(2)]
@@ -81,14 +87,15 @@ def _worker(rank, world, port, dtype_name, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("sharded", [False, True])
 @pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
-def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name):
+def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name, sharded):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q, sharded)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
@@ -100,3 +107,33 @@ def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name):
         assert ok_ref, "exchanged step differs from the single-process step on the mean gradient"
         assert all(l == l and l > 0 for l in losses)
     assert res[0][3] != res[1][3]            # the ranks did see different batches
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* from the env), with both
+    ranks on the ONE GPU of the test box and gloo as the process group: barrier, MAX-reduce of the elapsed time, rank-0-only
+    JSON line, whole-job value = 2 x per-GPU batch x steps / time, sharded exchange through the torch.distributed collectives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VCT_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                                       "--batch", "16", "--no-cpu-baseline", "--no-decode"], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    lines1 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not lines1                        # ONE JSON line, from rank 0
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 32 and d["config"]["grad_exchange"].startswith("sharded/")
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
+    assert d["loss"] == d["loss"] and "cpu_baseline" not in d

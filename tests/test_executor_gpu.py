@@ -154,3 +154,45 @@ def test_fused_attention_block_in_the_training_step(monkeypatch):
     assert abs(out[True][0] - out[False][0]) < 2e-3 * abs(out[False][0])
     g0, g1 = out[False][1].double(), out[True][1].double()
     assert float((g1 - g0).norm() / g0.norm()) < 3e-2
+
+
+@pytest.mark.parametrize("sharded", [True, False])
+@pytest.mark.parametrize("executor", ["eager", "list"])
+def test_own_rccl_communicator_world1_step_is_the_plain_step(sharded, executor):
+    """The library's RCCL communicator through the C ABI (vct_comm_*), world size 1 (the test box has one GPU): reduce-scatter ->
+    Adam on the owned shard -> all-gather (or all-reduce + Adam) per bucket on the communicator's stream must give bitwise
+    the parameters of the plain single-GPU step -- eagerly and as a recorded launch list."""
+    from vct_amd.comm import RcclColl
+    from vct_amd.trainer import CaptionTrainer, FusedAdam, ShardedExchange
+    ref, lref, _ = _run("eager", steps=4)
+    m = _model()
+    m._seed.fill_(1234)
+    opt = FusedAdam(m, lr=1e-3)
+    coll = RcclColl(device=torch.device("cuda", 0))
+    assert coll.world == 1 and coll.self_test()
+    ex = ShardedExchange(m, opt, coll, sharded=sharded)
+    tr = CaptionTrainer(m, opt, ex, launch_list=executor == "list")
+    assert tr.use_list == (executor == "list")
+    losses = torch.cat([tr.step(*_batch(100 + k)).clone() for k in range(4)])
+    torch.cuda.synchronize()
+    assert torch.equal(losses, lref)
+    assert torch.equal(m.flat_params, ref)
+    assert torch.equal(m._ps.cflat[:opt.skip[0]], m.flat_params[:opt.skip[0]].to(torch.bfloat16))
+    coll.close()
+
+
+def test_rccl_bf16_payload_world1_is_close_to_the_fp32_step():
+    from vct_amd.comm import RcclColl
+    from vct_amd.trainer import CaptionTrainer, FusedAdam, ShardedExchange
+    ref, _, _ = _run("eager", steps=2)
+    m = _model()
+    m._seed.fill_(1234)
+    opt = FusedAdam(m, lr=1e-3)
+    coll = RcclColl(device=torch.device("cuda", 0))
+    tr = CaptionTrainer(m, opt, ShardedExchange(m, opt, coll, payload_dtype=torch.bfloat16))
+    for k in range(2):
+        tr.step(*_batch(100 + k))
+    torch.cuda.synchronize()
+    e = m.caption_param_end
+    assert float((m.flat_params[:e] - ref[:e]).abs().max()) < 5e-3      # Adam normalises: a bf16-rounded gradient moves a weight <= 2 lr
+    coll.close()

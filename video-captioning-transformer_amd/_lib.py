@@ -79,6 +79,18 @@ _SIGS = {
     "vct_stream_wait": (C.c_int, [vp, vp]),
     "vct_sync_record": (C.c_int, [C.c_int, vp]),
     "vct_sync_wait": (C.c_int, [C.c_int, vp]),
+    "vct_comm_available": (C.c_int, []),
+    "vct_comm_unique_id": (C.c_int, [vp]),
+    "vct_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "vct_comm_destroy": (C.c_int, [vp]),
+    "vct_comm_rank": (C.c_int, [vp]),
+    "vct_comm_world": (C.c_int, [vp]),
+    "vct_comm_stream": (C.c_int, [vp, C.POINTER(vp)]),
+    "vct_comm_allreduce_avg": (C.c_int, [vp, vp, i64, C.c_int, vp, C.c_int]),
+    "vct_comm_reduce_scatter_avg": (C.c_int, [vp, vp, i64, C.c_int, vp, C.c_int]),
+    "vct_comm_all_gather": (C.c_int, [vp, vp, i64, C.c_int, vp, C.c_int]),
+    "vct_comm_broadcast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp, C.c_int]),
+    "vct_comm_wait": (C.c_int, [vp, vp]),
     "vct_stream_create_masked": (C.c_int, [C.POINTER(u32), C.c_int, C.POINTER(vp)]),
     "vct_stream_destroy": (C.c_int, [vp]),
     "vct_tap_enable": (C.c_int, [C.c_int]),
@@ -165,6 +177,8 @@ def check(rc, what):
         return
     if rc < 0:
         raise ValueError(f"{what}: {_ERR.get(rc, rc)}")
+    if rc >= 10000:
+        raise RuntimeError(f"{what}: ncclResult_t {rc - 10000}")
     raise RuntimeError(f"{what}: hipError_t {rc}")
 
 

@@ -9,7 +9,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvct_hip.so")
-SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_attn.hip", "vct_attn_block.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_runtime.hip"]
+SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_attn.hip", "vct_attn_block.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_runtime.hip", "vct_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
@@ -57,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(srcs)) as ex:
         objs = list(ex.map(cc, srcs))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

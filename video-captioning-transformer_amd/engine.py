@@ -87,6 +87,15 @@ class ParamSet:
             ops.cast(self.flat[a:b], self.cflat[a:b])
         self._stamp = stamp if stamp is not None else sum(p._version for p in self.params.values())
 
+    def cast_range(self, a: int, b: int):
+        """bf16 shadow <- fp32 masters for flat elements [a, b) (minus the tensors that have no shadow)."""
+        if self.compute_dtype == torch.float32:
+            return
+        for x, y in self.cast_ranges:
+            lo, hi = max(a, x), min(b, y)
+            if hi > lo:
+                ops.cast(self.flat[lo:hi], self.cflat[lo:hi])
+
     def install_grads(self):
         for n, p in self.params.items():
             if p.requires_grad and p.grad is not self.g[n]:

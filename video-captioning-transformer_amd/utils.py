@@ -42,7 +42,9 @@ def configure_hardware(backend: str = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available() and backend != "gloo"
+    backend = os.environ.get("VCT_DIST_BACKEND", backend)     # tests: several ranks on ONE GPU talk over gloo
     if use_cuda:
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -50,6 +52,6 @@ def configure_hardware(backend: str = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {"device_id": device} if use_cuda else {}
+        kw = {"device_id": device} if (use_cuda and backend in (None, "nccl")) else {}
         dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
     return device, rank, world
