@@ -170,6 +170,12 @@ def main():
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to the C-level stdout when a communicator is
+    # created, so everything else written to fd 1 by this process goes to stderr and the JSON goes to a private duplicate
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     import vct_amd  # noqa: F401
     from vct_amd import ops
@@ -237,6 +243,8 @@ def main():
                 payload = None
             ex = ShardedExchange(model, opt, coll, sharded=args.exchange == "sharded", payload_dtype=payload)
             exchange_kind = f"{args.exchange}/{'vct_comm' if coll.owns_stream else 'c10d'}"
+            if os.environ.get("VCT_COMM_IDLE") == "1":      # experiment: the communicator exists but carries nothing
+                ex, exchange_kind = None, "idle communicator"
         else:
             ex = GradExchange(model, payload_dtype=payload, force=args.force_exchange)
             exchange_kind = "allreduce/torch.distributed"
@@ -344,7 +352,8 @@ def main():
             out["decode"] = decode_line(device, model.compute_dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 

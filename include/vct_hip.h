@@ -300,7 +300,7 @@ int vct_sync_wait(int id, void* stream);
  * Gradient exchange over RCCL / xGMI (csrc/vct_comm.hip).  One communicator per process (one process per GPU).
  * replaces: DistributedDataParallel's bucketed NCCL all-reduce (train.py:217-219, utils.py:137-146).
  *   vct_comm_unique_id: rank 0 fills 128 bytes; the caller ships them to every rank (any side channel).
- *   vct_comm_init: collective over all ranks; the communicator owns a high-priority HIP stream for its collectives.
+ *   vct_comm_init: collective over all ranks; the communicator owns a HIP stream for its collectives.
  *   Collectives are IN PLACE on device buffers and asynchronous: enqueued on the communicator's stream, ordered behind
  *   everything enqueued so far on after_stream when order_after != 0 (after_stream may be the NULL stream):
  *     vct_comm_allreduce_avg       buf[0:count)              <- mean over ranks

@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include "../../include/vct_hip.h"
@@ -102,9 +103,18 @@ extern "C" int vct_comm_init(const uint8_t* id128, int rank, int world, void** o
   Comm* c = new (std::nothrow) Comm();
   if (c == nullptr) return (int)hipErrorOutOfMemory;
   c->rank = rank; c->world = world;
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);   // highest priority: never queue behind compute
+  // an ordinary (non-blocking) stream.  A high-priority stream was measured on MI355X and rejected: its mere existence
+  // slowed the compute streams' kernels by 10 %, and with collectives in flight on it every kernel of the step ran 2-3.5x
+  // slower (step 2.65 -> 7.7 ms at world size 1); VCT_COMM_PRIO=1 re-enables it for experiments.
+  static const char* prio_env = getenv("VCT_COMM_PRIO");
+  hipError_t e;
+  if (prio_env != nullptr && prio_env[0] == '1') {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) { delete c; return (int)e; }
   ncclUniqueId id;
   memcpy(id.internal, id128, 128);
