@@ -200,3 +200,33 @@ def test_torch_cpu_baseline_model_matches_the_oracle():
         mine = named[k].grad.numpy()
         err = np.linalg.norm(mine - g) / max(np.linalg.norm(g), 1e-30)
         assert err < 2e-4, (k, err)
+
+
+def test_oracle_vs_reference_cfgD_and_cfgB_decode():
+    """The deep configuration (6 + 6 layers, d = 1024, head_dim 128, 32 frames, 40 tokens, V = 30522, ragged batch of 8) and the
+    d=512 greedy decode at batch 1 / 16, recorded from the real reference by oracle/make_golden_cfgD.py."""
+    import json
+    GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(GOLDEN, "cfgD_slices.npz"), allow_pickle=False)
+    mc, V = json.loads(str(z["model_config"])), int(z["vocab"])
+    cfg = O.cfg_from_model_config(mc, V)
+    p = O.init_params(cfg, seed=int(z["param_seed"]))
+    f, mk, ids = O.synthetic_batch(8, 32, 512, 40, V, seed=int(z["batch_seed"]), ragged=True)
+    loss, grads, logits = O.caption_loss_and_grads(p, cfg, f, mk, ids)
+    assert abs(loss - float(z["loss"])) < 2e-6 * float(z["loss"])
+    lg = logits.reshape(8, 39, V)
+    np.testing.assert_allclose(lg[:, :, :64], z["logits_head"], rtol=2e-4, atol=2e-5)
+    names = json.loads(str(z["grad_names"]))
+    for i, k in enumerate(names):
+        n = float(np.linalg.norm(grads[k].astype(np.float64)))
+        assert abs(n - z["grad_norms"][i]) < 3e-5 * z["grad_norms"][i] + 1e-12, (k, n, z["grad_norms"][i])
+    zd = np.load(os.path.join(GOLDEN, "cfgB_decode.npz"), allow_pickle=False)
+    mcB = json.loads(str(zd["model_config"]))
+    cfgB = O.cfg_from_model_config(mcB, V)
+    pB = O.init_params(cfgB, seed=int(zd["param_seed"]))
+    fB = O.synthetic_batch(1, 12, 512, 20, V, seed=int(zd["feats_seed_b1"]))[0]
+    ys = O.greedy_decode_ids(pB, cfgB, fB, None, max_len=30)
+    m1 = zd["margins_b1"][0]
+    low = np.nonzero(m1 < 5e-5)[0]
+    upto = int(low[0]) + 1 if low.size else ys.shape[1]
+    assert np.array_equal(ys[0, :upto], zd["ys_b1"][0, :upto])
