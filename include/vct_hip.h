@@ -267,6 +267,41 @@ int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, i
 int vct_greedy_select(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
                       int64_t end_id, uint8_t* ended, int32_t* ended_count, int64_t* all_ended_at, int32_t t,
                       void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * One stage of the greedy-decode step at SMALL batch (B <= 4): out[b, n] = epilogue(W[n, :] . prologue(...)[b, :]), a weight-
+ * streaming matrix-vector kernel whose prologue builds the input vector and whose epilogue finishes the stage, so that the
+ * embedding / LayerNorm / attention launches of the per-token step vanish into their consumers (csrc/vct_decode.hip):
+ *   pro = VCT_DEC_PRO_NONE        x = x_in[b, 0:K)                                  (fp32)
+ *         VCT_DEC_PRO_EMBED       x = table[ids[b*id_stride], :] + pos_row          (nn.Embedding + PositionalEmbedding, CapDecoder.py:64-66)
+ *         VCT_DEC_PRO_LN          x = LayerNorm(x_in; g1, b1)                       (the previous stage stored the PRE-norm sum)
+ *         VCT_DEC_PRO_LN_LN       x = LayerNorm(LayerNorm(x_in; g1, b1); g2, b2)    (last layer's norm3, then decoder.norm)
+ *         VCT_DEC_PRO_SELF_ATTN / _CROSS_ATTN   x = MHA core of ONE query per batch row: q [B] rows (stride q_bs), keys / values
+ *                                 kc / vc + b*kv_bs + l*kv_ld for l < Lk (<= 64), H heads of K/H columns; no mask (CapDecoder.py:70-75:
+ *                                 the newest token attends to every cached position)
+ *   epilogue: + bias[n], act, + res[b*ld_res + n] (fp32), stored as fp32 or -- out_native -- in the weight dtype (q|k|v into the KV-cache
+ *   slot, logits).  x_out (optional, fp32 [B, K]): the prologue's vector, written once (the next stage's residual).
+ *   W: [N, K] row-major, wdtype VCT_BF16 (K % 512 == 0) or VCT_F32 (K % 256 == 0), K <= 2048; KV cache and q in the same dtype.
+ * replaces: per token and decoder layer, self_attn / multihead_attn (in_proj, SDPA, out_proj), linear1 / linear2, norm1-3 of
+ * nn.TransformerDecoderLayer (torch nn/modules/transformer.py:1143-1199) as called from CapDecoder.decode_word (CapDecoder.py:62-79),
+ * plus decoder.norm and the generator: 6 launches per layer + 1 instead of 11 + 2.
+ * --------------------------------------------------------------------------------------------- */
+enum { VCT_DEC_PRO_NONE = 0, VCT_DEC_PRO_EMBED = 1, VCT_DEC_PRO_LN = 2, VCT_DEC_PRO_LN_LN = 3, VCT_DEC_PRO_SELF_ATTN = 4,
+       VCT_DEC_PRO_CROSS_ATTN = 5 };
+typedef struct vct_decode_gemv_desc {
+  int32_t wdtype, B, N, K;
+  const void* W; int64_t ldw;
+  const float* bias;
+  int32_t pro, act;
+  const float* x_in; int64_t ld_x;
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  const int64_t* ids; int64_t id_stride; const float* table; const float* pos_row;
+  const void* q; int64_t q_bs; const void* kc; const void* vc; int64_t kv_ld, kv_bs; int32_t H, Lk;
+  const float* res; int64_t ld_res;
+  void* out; int64_t ld_out; int32_t out_native; int32_t rows_per_wave;   /* rows_per_wave: 0 = auto */
+  float* x_out;
+} vct_decode_gemv_desc;
+int vct_decode_gemv(const vct_decode_gemv_desc* d, void* stream);
+
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);
 

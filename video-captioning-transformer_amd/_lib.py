@@ -43,6 +43,17 @@ class AttnBlockDesc(C.Structure):
                 ("mean", vp), ("rstd", vp), ("site_res", u32), ("reserved", i32)]
 
 
+class DecodeGemvDesc(C.Structure):
+    _fields_ = [("wdtype", i32), ("B", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i64), ("bias", vp), ("pro", i32), ("act", i32),
+                ("x_in", vp), ("ld_x", i64), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp),
+                ("ids", vp), ("id_stride", i64), ("table", vp), ("pos_row", vp),
+                ("q", vp), ("q_bs", i64), ("kc", vp), ("vc", vp), ("kv_ld", i64), ("kv_bs", i64), ("H", i32), ("Lk", i32),
+                ("res", vp), ("ld_res", i64), ("out", vp), ("ld_out", i64), ("out_native", i32), ("rows_per_wave", i32),
+                ("x_out", vp)]
+
+
+DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}
+
 _SIGS = {
     "vct_abi_version": (C.c_int, []),
     "vct_build_info": (C.c_int, [C.c_char_p, C.c_int]),
@@ -65,6 +76,7 @@ _SIGS = {
     "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
+    "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),
     "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -738,5 +738,67 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
+def _decoder_small_decode_ok(self, st: DecodeState) -> bool:
+    """The weight-streaming GEMV step (ops.decode_gemv): model widths that are whole 16-byte lane rows (d, ff multiples of
+    512 for bf16 / 256 for fp32, <= 2048), <= 64 cached positions, and batch <= 2 -- measured per token at cfg-B
+    (tools/decode_probe.py, graph replay): batch 1 97 us vs 146 us on the batched MFMA kernels, batch 2 135 vs 146, batch 4
+    217 vs 149 (every workgroup recomputes the attention of all (batch, head) pairs and reduces 8 x B dot products per
+    trip), so larger batches stay on the batched kernels."""
+    ki = 512 if self.dt == torch.bfloat16 else 256
+    d, ff = self.cfg["d"], self.cfg["ff"]
+    return (self.small_batch_decode and st.B <= 2 and d % ki == 0 and ff % ki == 0 and d <= 2048 and ff <= 2048
+            and st.Lmax <= 64 and st.Te <= 64 and self.dev.type == "cuda")
+
+
+def _decoder_decode_step_small(self, st: DecodeState, t: int, end_id: int):
+    """The same step as _decoder_decode_step in 6 launches per layer + 2: embedding, LayerNorms and both attention cores run in the
+    prologues of the matrix-vector kernels that consume them, residual adds in the epilogues of the producers; activations
+    between stages are fp32 vectors (pre-norm sums s, normalised x kept for the next residual)."""
+    d, H, L, B, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax, self.cfg["ff"]
+    b = st.b
+    f32 = torch.float32
+    x, s, x1, x2 = (b.get(n, (B, d), f32) for n in ("sx", "ss", "sx1", "sx2"))
+    s2, s3 = b.get("ss2", (B, d), f32), b.get("ss3", (B, d), f32)
+    qc = b.get("sqc", (B, d), self.dt)
+    h = b.get("sh", (B, ff), f32)
+    prev_norm = None
+    for l in range(L):
+        lp = f"decoder.layers.{l}."
+        sa, ca = lp + "self_attn.", lp + "multihead_attn."
+        cache = st.kv_self[l]                                              # [B * Lmax, 3d]: q | k | v of every consumed token
+        slot = cache.view(B, Lmax, 3 * d)[:, t - 1, :]
+        if l == 0:      # x = Emb[ys[:, t-1]] + pos[t-1]  ->  q | k | v into slot t-1
+            ops.decode_gemv(self.W(sa + "in_proj_weight"), slot, B, bias=self.F(sa + "in_proj_bias"), pro="embed",
+                            embed=(st.ys[:, t - 1], self.F("tgt_to_emb.weight"), self.pos[t - 1]), out_native=True, x_out=x)
+        else:           # x = norm3 of the layer below
+            ops.decode_gemv(self.W(sa + "in_proj_weight"), slot, B, bias=self.F(sa + "in_proj_bias"), pro="ln", x_in=s3, ln1=prev_norm,
+                            out_native=True, x_out=x)
+        # s = x + out_proj(self-attention over the t cached positions)
+        ops.decode_gemv(self.W(sa + "out_proj.weight"), s, B, bias=self.F(sa + "out_proj.bias"), pro="self_attn",
+                        attn=(slot[:, :d], cache[:, d:2 * d], cache[:, 2 * d:], 3 * d, Lmax * 3 * d, H, t), res=x)
+        # x1 = norm1(s); cross-attention query
+        ops.decode_gemv(self.W(ca + "in_proj_weight")[:d], qc, B, bias=self.F(ca + "in_proj_bias")[:d], pro="ln", x_in=s,
+                        ln1=(self.F(lp + "norm1.weight"), self.F(lp + "norm1.bias")), out_native=True, x_out=x1)
+        kvc = st.kv_cross[l]                                               # [B * Te, 2d]
+        ops.decode_gemv(self.W(ca + "out_proj.weight"), s2, B, bias=self.F(ca + "out_proj.bias"), pro="cross_attn",
+                        attn=(qc, kvc[:, :d], kvc[:, d:], 2 * d, Te * 2 * d, H, Te), res=x1)
+        # x2 = norm2(s2); feed-forward
+        ops.decode_gemv(self.W(lp + "linear1.weight"), h, B, bias=self.F(lp + "linear1.bias"), pro="ln", x_in=s2,
+                        ln1=(self.F(lp + "norm2.weight"), self.F(lp + "norm2.bias")), act=self.cfg["activation"], x_out=x2)
+        ops.decode_gemv(self.W(lp + "linear2.weight"), s3, B, bias=self.F(lp + "linear2.bias"), pro="none", x_in=h, res=x2)
+        prev_norm = (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias"))
+    logits = b.get("slogits", (B, self.Vp), f32)
+    ops.decode_gemv(self.W("generator.weight"), logits, B, bias=self.F("generator.bias"), pro="ln_ln", x_in=s3, ln1=prev_norm,
+                    ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), n_valid=self.V)
+    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
+
+
+def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
+    if _decoder_small_decode_ok(self, st):
+        return _decoder_decode_step_small(self, st, t, end_id)
+    return _decoder_decode_step(self, st, t, end_id)
+
+
+DecoderEngine.small_batch_decode = True       # A/B switch: weight-streaming GEMV step for batch <= 4
 DecoderEngine.decode_begin = _decoder_decode_begin
-DecoderEngine.decode_step = _decoder_decode_step
+DecoderEngine.decode_step = _decoder_decode_step_any

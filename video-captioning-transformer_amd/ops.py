@@ -316,6 +316,34 @@ def greedy_select(x, out, end_id: int, ended, ended_count, all_ended_at, t: int,
     return out
 
 
+def decode_gemv(W, out, B, *, bias=None, pro="none", x_in=None, ln1=None, ln2=None, embed=None, attn=None, act=None, res=None,
+                out_native=False, ld_out=None, x_out=None, n_valid=None):
+    """One stage of the small-batch greedy-decode step (include/vct_hip.h, vct_decode_gemv).  W [N, K]; out: tensor whose row b starts
+    at out.data_ptr() + b*ld_out elements.  embed = (ids view [B] (any stride), table fp32, pos_row fp32 [K]);
+    attn = (q view [B, K], k view, v view, kv_ld, kv_bs, H, Lk) -- all in W's dtype; ln1 / ln2 = (gamma, beta)."""
+    d = L.DecodeGemvDesc()
+    d.wdtype, d.B, d.N, d.K = L.dtype_code(W.dtype), B, (n_valid or W.shape[0]), W.shape[1]
+    d.W, d.ldw, d.bias = W.data_ptr(), _ld(W), L.ptr(bias)
+    d.pro, d.act = L.DEC_PRO[pro], L.ACT[act]
+    if x_in is not None:
+        d.x_in, d.ld_x = x_in.data_ptr(), x_in.stride(0)
+    if ln1 is not None:
+        d.g1, d.b1 = ln1[0].data_ptr(), ln1[1].data_ptr()
+    if ln2 is not None:
+        d.g2, d.b2 = ln2[0].data_ptr(), ln2[1].data_ptr()
+    if embed is not None:
+        ids, table, pos_row = embed
+        d.ids, d.id_stride, d.table, d.pos_row = ids.data_ptr(), ids.stride(0), table.data_ptr(), pos_row.data_ptr()
+    if attn is not None:
+        q, k, v, kv_ld, kv_bs, H, Lk = attn
+        d.q, d.q_bs, d.kc, d.vc, d.kv_ld, d.kv_bs, d.H, d.Lk = q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), kv_ld, kv_bs, H, Lk
+    if res is not None:
+        d.res, d.ld_res = res.data_ptr(), res.stride(0)
+    d.out, d.ld_out, d.out_native = out.data_ptr(), (ld_out if ld_out is not None else out.stride(0)), int(out_native)
+    d.x_out = L.ptr(x_out)
+    L.check(L.load().vct_decode_gemv(d, L.stream_ptr()), "vct_decode_gemv")
+
+
 def gather_pad_rows(store: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, tmax: int, out_dtype=torch.float32):
     """store fp32 [rows, E] (packed clips), offsets int64 [n+1], idx int64 [B] -> (feat [B, tmax, E], mask bool [B, tmax])."""
     B, E = idx.numel(), store.shape[1]
