@@ -383,6 +383,7 @@ static int dispatch_layout(const vct_gemm_desc* d, const GemmP& p, int bm, dim3 
 }
 
 int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st);
+int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split);   // persistent 256x256 kernel (vct_gemm256.hip)
 
 }  // namespace vct
 
@@ -448,6 +449,22 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   const int ok = check_desc(d);
   if (ok != VCT_OK) return ok;
   hipStream_t st = (hipStream_t)stream;
+  {
+    bool used = false;
+    int rsplit = 1;
+    const int rc256 = gemm256_try(d, st, &used, &rsplit);
+    if (rc256 != VCT_OK) return rc256;
+    if (used) {
+      if (rsplit > 1) {     // fp32 partials [rsplit][M][N] in the workspace -> C (bf16)
+        const size_t total = (size_t)d->M * d->N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        vct::launch((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(d->workspace),
+                    reinterpret_cast<bf16_t*>(d->C), (long)d->ldc, d->M, d->N, rsplit, (const float*)nullptr, (float*)nullptr);
+        VCT_CHECK_LAUNCH();
+      }
+      return VCT_OK;
+    }
+  }
 
   const int64_t need = vct_gemm_workspace_bytes(d);
   const bool have_ws = d->workspace != nullptr && d->workspace_bytes >= need && need > 0;
