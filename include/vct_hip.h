@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 3
+#define VCT_ABI_VERSION 4
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -301,6 +301,40 @@ typedef struct vct_decode_gemv_desc {
   float* x_out;
 } vct_decode_gemv_desc;
 int vct_decode_gemv(const vct_decode_gemv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One nn.Linear of the greedy-decode step at LARGER batch (2 <= M = captions in flight <= 256), applied to the M rows of the
+ * current position:  out[M, N] = act(in W^T + bias) + res,  W bf16 [N, K] row-major (csrc/vct_gemm_skinny.hip: MFMA fragments
+ * straight from L2, K split over the eight waves of a workgroup, 16 output columns per workgroup).  Input, one of
+ *   x      bf16 rows (ldx)                                                    -- or --
+ *   x_pre  fp32 PRE-norm rows: in = LayerNorm(x_pre; ln_g, ln_b, eps 1e-5), normalised in registers (K <= 1024); with x_norm
+ *          the normalised rows are also stored (fp32, once) for the residual of a later call.  With ids (int64, row r at
+ *          ids[r * id_stride]) the rows are instead EMBEDDED: in = x_pre[ids[r]] + ln_b, x_pre = the fp32 table [V, K] and ln_b the
+ *          positional row (nn.Embedding + PositionalEmbedding, CapDecoder.py:64-66); ln_g is not read.
+ * res: rows of res_dtype (VCT_F32 or VCT_BF16) added after the activation.  out: bf16 or fp32 rows (ldo: e.g. a KV-cache slot).
+ * K % 8 == 0; pointers 16-byte aligned, leading dimensions multiples of 8 (bf16) / 4 (fp32).
+ * replaces: norm1 / norm2 / norm3 + the Linear that consumes them, and the `x + sublayer(x)` adds, of nn.TransformerDecoderLayer
+ * (torch nn/modules/transformer.py:1143-1199) as called per token from CapDecoder.decode_word (CapDecoder.py:62-79): 8 launches per
+ * layer instead of 11.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_decode_linear_desc {
+  int32_t M, N, K;
+  int32_t out_dtype, act, res_dtype;
+  const void* x; int64_t ldx;
+  const float* x_pre; int64_t ld_pre;
+  const float* ln_g; const float* ln_b;
+  float* x_norm; int64_t ld_norm;
+  const void* W; int64_t ldw;
+  const float* bias;
+  const void* res; int64_t ld_res;
+  void* out; int64_t ldo;
+  const int64_t* ids; int64_t id_stride;
+} vct_decode_linear_desc;
+int vct_decode_linear(const vct_decode_linear_desc* d, void* stream);
+/* y[M, K] (bf16) = LayerNorm(LayerNorm(x; g1, b1); g2, b2) of fp32 rows (g2 = b2 = NULL: one LayerNorm): the last layer's norm3
+ * followed by decoder.norm (CapDecoder.py:20) in front of the generator.  K <= 1024, K % 4 == 0. */
+int vct_decode_ln2(int M, int K, const float* x, int64_t ldx, const float* g1, const float* b1, const float* g2, const float* b2,
+                   void* y, int64_t ldy, void* stream);
 
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);

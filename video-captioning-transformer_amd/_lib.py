@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -52,6 +52,13 @@ class DecodeGemvDesc(C.Structure):
                 ("x_out", vp)]
 
 
+class DecodeLinearDesc(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("out_dtype", i32), ("act", i32), ("res_dtype", i32),
+                ("x", vp), ("ldx", i64), ("x_pre", vp), ("ld_pre", i64), ("ln_g", vp), ("ln_b", vp), ("x_norm", vp), ("ld_norm", i64),
+                ("W", vp), ("ldw", i64), ("bias", vp), ("res", vp), ("ld_res", i64), ("out", vp), ("ldo", i64),
+                ("ids", vp), ("id_stride", i64)]
+
+
 DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}
 
 _SIGS = {
@@ -77,6 +84,8 @@ _SIGS = {
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
+    "vct_decode_linear": (C.c_int, [C.POINTER(DecodeLinearDesc), vp]),
+    "vct_decode_ln2": (C.c_int, [C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),
     "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -25,7 +25,8 @@ def save_weights(model, path: str):
 
 def load_weights(model, path: str, map_location="cpu", strict: bool = False):
     """reference train.py:214-216: load_state_dict(torch.load(path), strict=False); returns the load report."""
-    return model.load_state_dict(torch.load(path, map_location=map_location), strict=strict)
+    # weights_only: a .pth from an untrusted source must not be able to run pickled code (tensors and containers only)
+    return model.load_state_dict(torch.load(path, map_location=map_location, weights_only=True), strict=strict)
 
 
 def _atomic_save(obj, path: str):
@@ -53,7 +54,8 @@ def save_training_state(path: str, model, optimizer=None, scheduler=None, epoch:
 
 def load_training_state(path: str, model, optimizer=None, scheduler=None, early_stopping=None) -> dict:
     """Restores everything save_training_state stored; returns {'epoch': next epoch to run, 'extra': ...}."""
-    state = torch.load(path, map_location="cpu", weights_only=False)
+    # tensors, numbers, strings and containers only (optimizer / scheduler state_dicts are plain data): no pickled code
+    state = torch.load(path, map_location="cpu", weights_only=True)
     if not isinstance(state, dict) or state.get("format") != FORMAT:
         raise ValueError(f"{path} is not a {FORMAT} file (a bare state_dict loads with load_weights)")
     missing, unexpected = model.load_state_dict(state["model"], strict=False)

@@ -236,8 +236,12 @@ __global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, in
   using P = PackT<T, VEC>;
   const int n = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const T* x = logits + (size_t)n * ldl;
-  const int64_t y = labels[(size_t)(n / S) * lbstride + (n % S)];
-  const bool valid = (y != pad_id);
+  const int64_t y_in = labels[(size_t)(n / S) * lbstride + (n % S)];
+  const bool valid = (y_in != pad_id);
+  // a label outside the vocabulary (torch raises a device assert there) must not become a stray read / write: the row is
+  // computed against column 0 and, when it counts towards the loss, poisons it with NaN so the step fails loudly
+  const bool oob = (y_in < 0 || y_in >= V);
+  const int64_t y = oob ? 0 : y_in;
   const float nvalid = row_ws[2 * N];
   const float xy = to_f<T>(x[y]);
   const int nv = (V + VEC - 1) / VEC;                 // vectors holding valid columns (ldl covers the rounded-up row)
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(NT, NT / 128) void sce_loss_kernel(int N, int S, in
     if (py >= 1e-7f) q -= py; else cnt -= 1.0f;        // remove the label column
   }
   if (tid == 0) {
-    row_ws[n] = valid ? (mx + __logf(se)) - xy : 0.0f;
+    row_ws[n] = valid ? (oob ? __builtin_nanf("") : (mx + __logf(se)) - xy) : 0.0f;
     row_ws[N + n] = SCE_C * (q + 1e-7f * cnt);
   }
   if (dlogits == nullptr) return;

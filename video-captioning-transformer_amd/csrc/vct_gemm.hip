@@ -384,6 +384,7 @@ static int dispatch_layout(const vct_gemm_desc* d, const GemmP& p, int bm, dim3 
 
 int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st);
 int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split);   // persistent 256x256 kernel (vct_gemm256.hip)
+int gemm_skinny_try(const vct_gemm_desc* d, hipStream_t st, bool* used);                    // M <= 256 rows (vct_gemm_skinny.hip)
 
 }  // namespace vct
 
@@ -438,6 +439,11 @@ static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
     const size_t out_bytes = (size_t)d->M * (size_t)d->N * (d->out_dtype == VCT_BF16 ? 2 : 4);
     p.nt_store = env != nullptr ? (env[0] == '1') : (out_bytes > ((size_t)64 << 20));
   }
+  {
+    static const char* env = getenv("VCT_GEMM_ORDER");       // A/B switch: 0 = grouped order always, 1 = short dimension fastest always
+    const int ts = pl.tiles_m < pl.tiles_n ? pl.tiles_m : pl.tiles_n;
+    p.short_fast = env != nullptr ? (env[0] == '1') : (pl.split > 1 && ts <= 4);
+  }
   if (pl.split > 1) {
     if (use_counters(d, pl)) p.counters = d->tile_counters;
     p.partial = reinterpret_cast<float*>(d->workspace);
@@ -449,6 +455,11 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   const int ok = check_desc(d);
   if (ok != VCT_OK) return ok;
   hipStream_t st = (hipStream_t)stream;
+  {
+    bool used = false;
+    const int rcs = gemm_skinny_try(d, st, &used);
+    if (rcs != VCT_OK || used) return rcs;
+  }
   {
     bool used = false;
     int rsplit = 1;

@@ -39,6 +39,7 @@ struct G256P {
   float* bias_grad;             // TN form: [M] row sums of op(A) (db = column sums of dlogits), n-tile 0 only
   float* partial;               // split > 1: fp32 partials [split][M][N] instead of C
   int nt_store;
+  int order;                    // tile order inside the flat work stream (see item())
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
 };
 
@@ -73,7 +74,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
   auto item = [&](int w, int& m0, int& n0, int& z, int& k_lo, int& k_hi) {
     const int tile = w / p.split;
     z = w - tile * p.split;
-    m0 = (tile % p.tiles_m) * G256_BM; n0 = (tile / p.tiles_m) * G256_BN;
+    if (p.order == 0) {                                      // M fastest
+      m0 = (tile % p.tiles_m) * G256_BM; n0 = (tile / p.tiles_m) * G256_BN;
+    } else {                                                 // groups of 8 tile columns, inside a group N fastest, then M: the 32
+      const int per_group = 8 * p.tiles_m;                   // workgroups of an XCD hold 4 x 8 tiles = 1 MB of A + 2 MB of B at a
+      const int grp = tile / per_group, rem = tile - grp * per_group;   // time and the 8 B panels stay for the whole sweep over M
+      const int gw = min(8, p.tiles_n - grp * 8);
+      m0 = (rem / gw) * G256_BM; n0 = (grp * 8 + rem % gw) * G256_BN;
+    }
     k_lo = z * p.kt_per_split; k_hi = min(nkt, k_lo + p.kt_per_split);
   };
   auto issue = [&](int m0, int n0, int kt, int buf) {
@@ -266,6 +274,7 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   p.kt_per_split = nkt;
   p.nt_store = ((size_t)d->M * d->N * (d->out_dtype == VCT_BF16 ? 2 : 4) > ((size_t)64 << 20)) ? 1 : 0;
   { static const char* ntenv = getenv("VCT_GEMM_NT"); if (ntenv != nullptr) p.nt_store = ntenv[0] == '1'; }
+  { static const char* oenv = getenv("VCT_GEMM256_ORDER"); p.order = oenv != nullptr ? atoi(oenv) : 1; }
   static const char* denv = getenv("VCT_GEMM256_DBG");
   p.dbg = denv != nullptr ? atoi(denv) : 0;
   const long tiles = (long)p.tiles_m * p.tiles_n;

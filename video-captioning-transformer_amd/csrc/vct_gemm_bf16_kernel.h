@@ -171,7 +171,11 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
     const int per_group = GRP * ts;
     const int grp = wgid / per_group, rem = wgid - grp * per_group;
     const int gsz = min(GRP, tl - grp * GRP);           // last group may be short
-    const int tshort = rem / gsz, tlong = grp * GRP + rem % gsz;
+    int tshort = rem / gsz, tlong = grp * GRP + rem % gsz;
+    // K-long operands (the vocabulary-deep dX): a tile's operand slabs are megabytes and never stay resident, so the only
+    // reuse is between tiles that stream the SAME slab at the same time -- the ts tiles of one long-dimension index become
+    // neighbours (same XCD, dispatched back to back) and the big operand is pulled from HBM once instead of once per XCD
+    if (p.short_fast) { tlong = wgid / ts; tshort = wgid - tlong * ts; }
     tile_m = n_long ? tshort : tlong;
     tile_n = n_long ? tlong : tshort;
   }

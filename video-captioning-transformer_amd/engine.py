@@ -740,13 +740,13 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
 
 def _decoder_small_decode_ok(self, st: DecodeState) -> bool:
     """The weight-streaming GEMV step (ops.decode_gemv): model widths that are whole 16-byte lane rows (d, ff multiples of
-    512 for bf16 / 256 for fp32, <= 2048), <= 64 cached positions, and batch <= 2 -- measured per token at cfg-B
-    (tools/decode_probe.py, graph replay): batch 1 97 us vs 146 us on the batched MFMA kernels, batch 2 135 vs 146, batch 4
-    217 vs 149 (every workgroup recomputes the attention of all (batch, head) pairs and reduces 8 x B dot products per
-    trip), so larger batches stay on the batched kernels."""
+    512 for bf16 / 256 for fp32, <= 2048), <= 64 cached positions, and batch 1 -- measured per token at cfg-B
+    (tools/decode_probe.py, graph replay): batch 1 97 us vs 114 us on the batched MFMA kernels, batch 2 135 vs 116 (every
+    workgroup recomputes the attention of all (batch, head) pairs and reduces 8 x B dot products per trip), so every larger
+    batch stays on the batched kernels."""
     ki = 512 if self.dt == torch.bfloat16 else 256
     d, ff = self.cfg["d"], self.cfg["ff"]
-    return (self.small_batch_decode and st.B <= 2 and d % ki == 0 and ff % ki == 0 and d <= 2048 and ff <= 2048
+    return (self.small_batch_decode and st.B <= 1 and d % ki == 0 and ff % ki == 0 and d <= 2048 and ff <= 2048
             and st.Lmax <= 64 and st.Te <= 64 and self.dev.type == "cuda")
 
 
@@ -793,10 +793,70 @@ def _decoder_decode_step_small(self, st: DecodeState, t: int, end_id: int):
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
+def _decoder_fused_decode_ok(self, st: DecodeState) -> bool:
+    """The batched step with LayerNorms folded into the consuming projections (ops.decode_linear): bf16, up to 256 captions in
+    flight, model width <= 1024 (a row's statistics come out of one pass over the MFMA fragments)."""
+    d, ff = self.cfg["d"], self.cfg["ff"]
+    return (self.fused_decode and self.dt == torch.bfloat16 and 2 <= st.B <= 256 and d % 32 == 0 and d <= 1024 and ff % 32 == 0
+            and self.dev.type == "cuda")
+
+
+def _decoder_decode_step_fused(self, st: DecodeState, t: int, end_id: int):
+    """The same step as _decoder_decode_step in 8 launches per layer + 3 instead of 11 + 4: every projection is one skinny MFMA
+    kernel (M = batch rows, K split over the waves); norm1 / norm2 / norm3 run as the prologue of the projection that consumes
+    them (which also stores the normalised rows once, for the residual two launches later), the residual adds in the epilogues;
+    the sums that feed a LayerNorm stay fp32."""
+    d, H, L, Bn, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax, self.cfg["ff"]
+    b = st.b
+    f32 = torch.float32
+    act = self.cfg["activation"]
+    xin, xres, prev_norm = None, None, None      # layer input: the embedded tokens (layer 0) or (pre-norm sum, norm3 of the layer below)
+    for l in range(L):
+        lp, tag = f"decoder.layers.{l}.", f"F{l}."
+        sa, ca = lp + "self_attn.", lp + "multihead_attn."
+        cache = st.kv_self[l]
+        slot = cache.view(Bn, Lmax, 3 * d)[:, t - 1, :]                     # q | k | v of the consumed token
+        xres = b.get(tag + "xn", (Bn, d), f32)
+        if prev_norm is None:                    # x = Emb[ys[:, t-1]] + pos[t-1], built in the projection's prologue
+            ops.decode_linear(self.W(sa + "in_proj_weight"), slot, embed=(st.ys[:, t - 1], self.F("tgt_to_emb.weight"), self.pos[t - 1]),
+                              x_norm=xres, bias=self.F(sa + "in_proj_bias"))
+        else:
+            ops.decode_linear(self.W(sa + "in_proj_weight"), slot, x_pre=xin, ln=prev_norm, x_norm=xres, bias=self.F(sa + "in_proj_bias"))
+        o = b.get(tag + "o", (Bn, d), self.dt)
+        ops.attn_fwd(slot[:, :d], cache[:, d:2 * d], cache[:, 2 * d:], o, Bn, H, 1, t, kv_batch_stride=Lmax * 3 * d)
+        s1 = b.get(tag + "s1", (Bn, d), f32)                                # x + self-attention block
+        ops.decode_linear(self.W(sa + "out_proj.weight"), s1, x=o, bias=self.F(sa + "out_proj.bias"), res=xres)
+        x1 = b.get(tag + "x1", (Bn, d), f32)
+        qc = b.get(tag + "qc", (Bn, d), self.dt)
+        ops.decode_linear(self.W(ca + "in_proj_weight")[:d], qc, x_pre=s1, ln=(self.F(lp + "norm1.weight"), self.F(lp + "norm1.bias")),
+                          x_norm=x1, bias=self.F(ca + "in_proj_bias")[:d])
+        oc = b.get(tag + "oc", (Bn, d), self.dt)
+        ops.attn_fwd(qc, st.kv_cross[l][:, :d], st.kv_cross[l][:, d:], oc, Bn, H, 1, Te)
+        s2 = b.get(tag + "s2", (Bn, d), f32)
+        ops.decode_linear(self.W(ca + "out_proj.weight"), s2, x=oc, bias=self.F(ca + "out_proj.bias"), res=x1)
+        x2 = b.get(tag + "x2", (Bn, d), f32)
+        h = b.get(tag + "h", (Bn, ff), self.dt)
+        ops.decode_linear(self.W(lp + "linear1.weight"), h, x_pre=s2, ln=(self.F(lp + "norm2.weight"), self.F(lp + "norm2.bias")),
+                          x_norm=x2, bias=self.F(lp + "linear1.bias"), act=act)
+        s3 = b.get(tag + "s3", (Bn, d), f32)
+        ops.decode_linear(self.W(lp + "linear2.weight"), s3, x=h, bias=self.F(lp + "linear2.bias"), res=x2)
+        xin, prev_norm = s3, (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias"))
+    y = b.get("fy", (Bn, d), self.dt)
+    ops.decode_ln2(xin, prev_norm, (self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), y)
+    logits = b.get("logits", (Bn, self.Vp), self.dt)
+    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=self.gemm_ws())
+    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
+
+
 def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
     if _decoder_small_decode_ok(self, st):
         return _decoder_decode_step_small(self, st, t, end_id)
+    if _decoder_fused_decode_ok(self, st):
+        return _decoder_decode_step_fused(self, st, t, end_id)
     return _decoder_decode_step(self, st, t, end_id)
+
+
+DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 
 DecoderEngine.small_batch_decode = True       # A/B switch: weight-streaming GEMV step for batch <= 4

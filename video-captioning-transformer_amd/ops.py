@@ -344,6 +344,41 @@ def decode_gemv(W, out, B, *, bias=None, pro="none", x_in=None, ln1=None, ln2=No
     L.check(L.load().vct_decode_gemv(d, L.stream_ptr()), "vct_decode_gemv")
 
 
+def decode_linear(W, out, *, x=None, x_pre=None, ln=None, x_norm=None, bias=None, act=None, res=None, n_valid=None, embed=None):
+    """One nn.Linear of the batched greedy-decode step on the M <= 256 rows of the current position (include/vct_hip.h,
+    vct_decode_linear): out = act(in W^T + bias) + res with in = x (bf16 rows) or LayerNorm(x_pre; *ln) of fp32 pre-norm rows
+    (x_norm: fp32 buffer that receives the normalised rows), or the embedded token rows: embed = (ids view [M] (any stride),
+    table fp32 [V, K], pos_row fp32 [K]).  out / res: row views (any row stride)."""
+    d = L.DecodeLinearDesc()
+    d.M, d.N, d.K = out.shape[0], (n_valid or W.shape[0]), W.shape[1]
+    d.out_dtype, d.act = L.dtype_code(out.dtype), L.ACT[act]
+    if x is not None:
+        d.x, d.ldx = x.data_ptr(), x.stride(0)
+    if x_pre is not None:
+        d.x_pre, d.ld_pre = x_pre.data_ptr(), x_pre.stride(0)
+        d.ln_g, d.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
+    if embed is not None:
+        ids, table, pos_row = embed
+        d.x_pre, d.ld_pre, d.ln_b = table.data_ptr(), table.stride(0), pos_row.data_ptr()
+        d.ids, d.id_stride = ids.data_ptr(), ids.stride(0)
+    if x_norm is not None:
+        d.x_norm, d.ld_norm = x_norm.data_ptr(), x_norm.stride(0)
+    d.W, d.ldw, d.bias = W.data_ptr(), _ld(W), L.ptr(bias)
+    if res is not None:
+        d.res, d.ld_res, d.res_dtype = res.data_ptr(), res.stride(0), L.dtype_code(res.dtype)
+    d.out, d.ldo = out.data_ptr(), out.stride(0)
+    L.check(L.load().vct_decode_linear(d, L.stream_ptr()), "vct_decode_linear")
+    return out
+
+
+def decode_ln2(x, ln1, ln2, y):
+    """y (bf16 [M, K]) = LayerNorm(LayerNorm(x; *ln1); *ln2) of fp32 rows; ln2 = None: one LayerNorm."""
+    g2, b2 = (ln2[0].data_ptr(), ln2[1].data_ptr()) if ln2 is not None else (None, None)
+    L.check(L.load().vct_decode_ln2(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), ln1[0].data_ptr(), ln1[1].data_ptr(), g2, b2,
+                                    y.data_ptr(), y.stride(0), L.stream_ptr()), "vct_decode_ln2")
+    return y
+
+
 def gather_pad_rows(store: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, tmax: int, out_dtype=torch.float32):
     """store fp32 [rows, E] (packed clips), offsets int64 [n+1], idx int64 [B] -> (feat [B, tmax, E], mask bool [B, tmax])."""
     B, E = idx.numel(), store.shape[1]
