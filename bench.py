@@ -337,7 +337,7 @@ def main():
                        "executor": "eager" if not (trainer.use_list or trainer.use_graph) else ("list" if trainer.use_list else "graph")},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),
-            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd 4864x30522x512 (gemm_bf16_v2_kernel NT, 128x128 tile, 8 waves, LDS-DMA double buffer)",
+            "roofline": {"bound": "mfma", "kernel": {"gen_fwd": "generator GEMM fwd 4864x30522x512 (gemm256_kernel NT: persistent 256x256 tiles, 8 waves, LDS-DMA double buffer)",
                                                      "gen_dx": "generator dX GEMM (vct_gemm NN)",
                                                      "gen_dw": "generator dW GEMM (vct_gemm TN)"}[dom],
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -257,6 +257,10 @@ int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 /* first-index argmax per row (torch.max(dim=1) tie-break, MMT4Caption.py:165); out[row * out_stride] int64
  * (out_stride lets the decode loop write straight into column t of the id matrix ys[B, max_len]) */
+/* dst[c, r] = src[r, c] (bf16 only): the transposed shadow of the vocabulary projection's weight, so that the input gradient
+ * dX = dlogits W_g runs in the K-contiguous NT form (replaces nothing in the reference: autograd's `grad_output.mm(weight)`,
+ * torch F.linear backward, reads W_g row-major). */
+int vct_transpose(int dtype, int rows, int cols, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, void* stream);
 int vct_argmax_rows(int dtype, int rows, int cols, const void* x, int64_t ldx, int64_t* out, int64_t out_stride,
                     void* stream);
 /* one greedy-decode selection step: vct_argmax_rows into column t of the id matrix PLUS the loop's end bookkeeping

@@ -105,6 +105,16 @@ def test_preprocessor_pads_and_masks():
         pre(["a raw string needs the tokenizer files"]); assert False
     except RuntimeError:
         pass
+    assert pre.tokenizer_error is None                 # "ids" asks for the pass-through: nothing failed
+    # a named HF tokenizer whose files are not on this machine: the fallback is announced at construction and the reason
+    # travels into the later encode() error
+    import pytest
+    with pytest.warns(RuntimeWarning, match="could not be loaded"):
+        pre2 = CapPreprocessor("no-such-tokenizer-dir/bert-base-uncased", device=torch.device("cpu"))
+    assert pre2.tokenizer_error
+    with pytest.raises(RuntimeError, match="loading the tokenizer failed"):
+        pre2(["a string"])
+    assert pre2([[101, 3, 102]])[0].tolist() == [[101, 3, 102]]
 
 
 def test_mask_builder_and_config(tmp_path):

@@ -83,6 +83,7 @@ _SIGS = {
     "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
+    "vct_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
     "vct_decode_linear": (C.c_int, [C.POINTER(DecodeLinearDesc), vp]),
     "vct_decode_ln2": (C.c_int, [C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp]),

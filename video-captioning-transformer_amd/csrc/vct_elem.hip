@@ -626,6 +626,71 @@ extern "C" int vct_advance_seed(uint32_t* seed, void* stream) {
   return VCT_OK;
 }
 
+// dst[c][r] = src[r][c] for 2-byte elements: 64x64 tiles through LDS.  Loads are 16-byte vectors along the source rows (128-byte
+// row segments), each thread then gathers eight elements DOWN a column of the tile (lanes = consecutive columns: conflict-free
+// 2-byte LDS reads) and stores them as one 16-byte vector of the destination row.  VEC: both leading dimensions multiples of 8 and
+// both bases 16-byte aligned; otherwise the element-wise form.
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose16_kernel(int rows, int cols, const uint16_t* __restrict__ src, int64_t lds_,
+                                                          uint16_t* __restrict__ dst, int64_t ldd) {
+  constexpr int STR = 72;                                    // LDS row stride in elements (144 B: 16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64 * STR];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+  struct alignas(16) V8 { uint16_t e[8]; };
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = (t >> 3) + 32 * i, ch = t & 7;
+      const int r = r0 + row, c = c0 + ch * 8;
+      V8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v.e[j] = 0;
+      if (r < rows) {
+        if (c + 8 <= cols) v = *reinterpret_cast<const V8*>(src + (size_t)r * lds_ + c);
+        else for (int j = 0; j < 8; j++) if (c + j < cols) v.e[j] = src[(size_t)r * lds_ + c + j];
+      }
+      *reinterpret_cast<V8*>(tile + row * STR + ch * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int cc = t & 63, ch = (t >> 6) + 4 * i;          // output row c0 + cc, its elements r0 + ch*8 .. +8
+      V8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v.e[j] = tile[(ch * 8 + j) * STR + cc];
+      const int c = c0 + cc, r = r0 + ch * 8;
+      if (c < cols && r < rows) {
+        if (r + 8 <= rows) *reinterpret_cast<V8*>(dst + (size_t)c * ldd + r) = v;
+        else for (int j = 0; j < 8; j++) if (r + j < rows) dst[(size_t)c * ldd + r + j] = v.e[j];
+      }
+    }
+  } else {
+    const int tx = t & 63, ty = t >> 6;
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[i * STR + tx] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[tx * STR + i];
+    }
+  }
+}
+
+extern "C" int vct_transpose(int dtype, int rows, int cols, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, void* stream) {
+  if (dtype != VCT_BF16 || src == nullptr || dst == nullptr) return VCT_E_ARG;
+  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return VCT_E_SHAPE;
+  const bool vec = (ld_src % 8 == 0) && (ld_dst % 8 == 0) && (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 15) == 0);
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (vec) vct::launch(transpose16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, rows, cols,
+                       reinterpret_cast<const uint16_t*>(src), ld_src, reinterpret_cast<uint16_t*>(dst), ld_dst);
+  else vct::launch(transpose16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, rows, cols,
+                   reinterpret_cast<const uint16_t*>(src), ld_src, reinterpret_cast<uint16_t*>(dst), ld_dst);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
 extern "C" int vct_abi_version(void) { return VCT_ABI_VERSION; }
 extern "C" int vct_build_info(char* buf, int buflen) {
   static const char info[] = "libvct_hip gfx950 (CDNA4) abi 2; bf16 mfma 16x16x32 + f32 mfma 16x16x4";

@@ -40,6 +40,7 @@ struct G256P {
   float* partial;               // split > 1: fp32 partials [split][M][N] instead of C
   int nt_store;
   int order;                    // tile order inside the flat work stream (see item())
+  int zmajor;                   // split > 1: K split outermost (tiles that share the A rows of one K range are neighbours)
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
 };
 
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
   const int nkt = (p.K + BK2 - 1) / BK2, kt_full = p.K / BK2;
 
   auto item = [&](int w, int& m0, int& n0, int& z, int& k_lo, int& k_hi) {
-    const int tile = w / p.split;
-    z = w - tile * p.split;
+    int tile;
+    if (p.zmajor) { const int nt = p.tiles_m * p.tiles_n; z = w / nt; tile = w - z * nt; }
+    else { tile = w / p.split; z = w - tile * p.split; }
     if (p.order == 0) {                                      // M fastest
       m0 = (tile % p.tiles_m) * G256_BM; n0 = (tile / p.tiles_m) * G256_BN;
     } else {                                                 // groups of 8 tile columns, inside a group N fastest, then M: the 32
@@ -253,12 +255,12 @@ template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hi
 int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split) {
   *used = false;
   *reduce_split = 1;
-  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN.  Default 1: measured on the same box (tools/gemm_bench.py
+  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN, 8 = NT split over K (narrow output).  Default 9: measured on the same box (tools/gemm_bench.py
   // --auto, cfg-B vocabulary shapes) NT 214 vs 253 us on the 128x128 kernel, but NN 260 vs 249 and TN 222 vs 193 -- the forms
   // whose operands go through the LDS transpose read need twice the fragment reads and spill at 256 VGPRs; they stay available
   // (and tested) behind the mask.
   static const char* env = getenv("VCT_GEMM256");
-  const int mask = env != nullptr ? atoi(env) : 1;
+  const int mask = env != nullptr ? atoi(env) : 9;
   if (mask == 0 || d->dtype != VCT_BF16 || d->reserved != 0) return VCT_OK;
   if (d->act != VCT_ACT_NONE || d->preact || d->addend || d->dact_src || (d->seed && d->p_drop > 0.0f)) return VCT_OK;
   const int form = d->ta * 2 + d->tb;                         // 1 NT, 0 NN, 2 TN
@@ -278,6 +280,26 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   static const char* denv = getenv("VCT_GEMM256_DBG");
   p.dbg = denv != nullptr ? atoi(denv) : 0;
   const long tiles = (long)p.tiles_m * p.tiles_n;
+  p.zmajor = 0;
+  if (form == 1 && (mask & 8) && d->out_dtype == VCT_BF16 && !d->bias && !d->bias_grad && d->split_k != 1 && d->workspace != nullptr &&
+      tiles <= 128 && nkt >= 128 && d->M >= 2048) {
+    // NT with a vocabulary-long K and a narrow output (dX = dlogits W_g through the transposed weight shadow): split over K so that
+    // every CU gets one item, fp32 partials + reduce.  K split outermost, N fastest inside: the tiles that read the same rows of
+    // the 297 MB A operand sit on neighbouring CUs of one XCD and pull them from HBM once.
+    int split = d->split_k > 1 ? d->split_k : (int)(256 / tiles);
+    if (split >= 2) {
+      p.kt_per_split = (nkt + split - 1) / split;
+      p.split = (nkt + p.kt_per_split - 1) / p.kt_per_split;
+      if ((int64_t)p.split * d->M * d->N * 4 <= d->workspace_bytes) {
+        p.partial = reinterpret_cast<float*>(d->workspace);
+        p.nt_store = 0; p.zmajor = 1; p.order = 1;
+        const int rc = g256_launch<0, 1, float>(p, st);
+        if (rc == VCT_OK) { *used = true; *reduce_split = p.split; }
+        return rc;
+      }
+      p.split = 1; p.kt_per_split = nkt; p.partial = nullptr;
+    }
+  }
   if (form == 1) {             // NT: vocabulary projection forward (bf16 out, bias)
     if (!(mask & 1) || d->out_dtype != VCT_BF16 || d->bias_grad || d->split_k > 1) return VCT_OK;
     if (d->M < 2048 || d->N < 8192 || (d->K % 8) || (d->ldc % 8) || ((uintptr_t)d->C & 15)) return VCT_OK;

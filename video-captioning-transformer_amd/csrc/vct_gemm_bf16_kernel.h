@@ -80,7 +80,17 @@ __device__ __forceinline__ void tail_tile(unsigned char* lds, const bf16_t* __re
     if constexpr (!MC) {
       const int row = v >> 3, c = v & 7;
       const int gr = r0 + row, gk = k0 + c * 8;
-      if (gr < r_ext && gk < K) val = *reinterpret_cast<const V16b*>(base + (long)gr * ld + gk);
+      if (gr < r_ext && gk < K) {
+        val = *reinterpret_cast<const V16b*>(base + (long)gr * ld + gk);
+        if (gk + 8 > K) {                 // K % 8 != 0: elements past K are dropped here, whatever the buffer's padding holds
+          const int keep = K - gk;        // 1..7 valid elements
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (2 * q >= keep) val.w[q] = 0u;
+            else if (2 * q + 1 >= keep) val.w[q] &= 0xffffu;
+          }
+        }
+      }
       *reinterpret_cast<V16b*>(lds + kc_off(row, c)) = val;
     } else {
       constexpr int CPRW = R / 8;

@@ -1,6 +1,7 @@
 """Caption -> padded id tensor + pad mask (reference: model/CapPreprocessor.py:7-36).  Host-side
 input preparation, not accelerated.  Accepts raw strings (needs the HF tokenizer files locally) or
 pre-tokenised id sequences (lists / tensors), which is what the synthetic benchmarks feed."""
+import warnings
 from typing import List, Sequence, Tuple, Union
 
 import torch
@@ -9,6 +10,7 @@ import torch
 class _IdTokenizer:
     """Stand-in when the `bert-base-uncased` vocabulary is not available offline: ids pass through."""
     vocab_size = 30522
+    reason = None          # why the real tokenizer is absent (set by CapPreprocessor)
 
     def convert_tokens_to_ids(self, tok):
         return {"[PAD]": 0, "[CLS]": 101, "[SEP]": 102}[tok]
@@ -20,21 +22,28 @@ class _IdTokenizer:
         return " ".join(toks)
 
     def encode(self, text, **_):
-        raise RuntimeError("no tokenizer vocabulary available offline: pass pre-tokenised id lists instead of strings")
+        raise RuntimeError("no tokenizer vocabulary available offline: pass pre-tokenised id lists instead of strings"
+                           + (f" (loading the tokenizer failed with: {self.reason})" if self.reason else ""))
 
 
 class CapPreprocessor:
     def __init__(self, tokenizer_type, device=torch.device("cuda"), vocab_size=None):
         self.tokenizer_type, self.device = tokenizer_type, device
+        self.tokenizer_error = None         # set when the requested HF tokenizer could not be loaded (id pass-through in use)
         tok = None
         if isinstance(tokenizer_type, str) and tokenizer_type not in ("stub", "ids"):
             try:
                 from transformers import AutoTokenizer
                 tok = AutoTokenizer.from_pretrained(tokenizer_type, local_files_only=True)
-            except Exception:
+            except Exception as e:      # no vocabulary files on this machine: say so NOW, not at the first encode()
                 tok = None
+                self.tokenizer_error = f"{type(e).__name__}: {e}"
+                warnings.warn(f"CapPreprocessor: tokenizer '{tokenizer_type}' could not be loaded from local files "
+                              f"({self.tokenizer_error}); captions must be passed as id sequences (strings will raise)",
+                              RuntimeWarning, stacklevel=2)
         if tok is None:
             tok = _IdTokenizer()
+            tok.reason = getattr(self, "tokenizer_error", None)
             if vocab_size is not None:
                 tok.vocab_size = vocab_size
         self.tokenizer = tok

@@ -344,6 +344,13 @@ def decode_gemv(W, out, B, *, bias=None, pro="none", x_in=None, ln1=None, ln2=No
     L.check(L.load().vct_decode_gemv(d, L.stream_ptr()), "vct_decode_gemv")
 
 
+def transpose(src: torch.Tensor, dst: torch.Tensor):
+    """dst[c, r] = src[r, c] (bf16; row strides free)."""
+    L.check(L.load().vct_transpose(L.dtype_code(src.dtype), src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
+                                   dst.data_ptr(), dst.stride(0), L.stream_ptr()), "vct_transpose")
+    return dst
+
+
 def decode_linear(W, out, *, x=None, x_pre=None, ln=None, x_norm=None, bias=None, act=None, res=None, n_valid=None, embed=None):
     """One nn.Linear of the batched greedy-decode step on the M <= 256 rows of the current position (include/vct_hip.h,
     vct_decode_linear): out = act(in W^T + bias) + res with in = x (bf16 rows) or LayerNorm(x_pre; *ln) of fp32 pre-norm rows
