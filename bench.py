@@ -118,7 +118,8 @@ def cpu_baseline(budget_s=24.0):
 
 
 def decode_line(device, dtype):
-    """configs[4]: greedy decode (KV cache + captured per-token step) of the cfg-B model in eval mode, batch 1 and 128.
+    """configs[4]: greedy decode (KV cache + captured per-token step) of the cfg-B model in eval mode, batch 1 and 128:
+    whole-call time per token step (encoder forward, memory K/V projection and host checks included) and the step alone.
     A FRESH random-init model: it practically never emits [SEP], so every caption runs the full 29 steps (the trained-
     for-30-steps bench model stops after one).  Reported beside the training metric; not the headline value."""
     from vct_amd.model import MMT4Caption
@@ -140,6 +141,19 @@ def decode_line(device, dtype):
         dt = (time.perf_counter() - t0) / n
         steps = ys.shape[1] - 1
         out[f"batch{B}"] = {"us_per_token_step": round(dt / steps * 1e6, 1), "tokens_per_s": round(B * steps / dt, 1), "steps": steps}
+        # the token step alone (its captured graphs replayed back to back, HIP events): without the encoder forward, the
+        # cross-attention K/V projection of the memory and the host's end-of-sequence check every 4 tokens
+        st = next((s for k, s in model.__dict__.get("_decode_sessions", {}).items() if k[0] == B), None)
+        if st is not None and all(t in st.graphs for t in range(1, 30)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                for t in range(1, 30):
+                    st.graphs[t].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            out[f"batch{B}"]["us_per_step_replay_only"] = round(e0.elapsed_time(e1) * 1e3 / (reps * 29), 1)
     return out
 
 

@@ -303,6 +303,18 @@ def test_kv_cache_graph_decode_equals_reference_algorithm(dtype):
     assert torch.equal(a, b)
     if dtype == torch.float32:
         assert torch.equal(a, m.greedy_decode_ids([feats2], None, max_len=30, kv_cache=False))
+    # the captured prologue (encoder forward + memory K/V) bakes pointers into the engines' shared grow-only buffers: a larger
+    # batch through the same engines re-allocates them, after which the small session must re-capture, not replay stale pointers
+    big = torch.from_numpy(O.synthetic_batch(24, 12, 512, 20, 30522, seed=5)[0]).to(DEV)
+    m.greedy_decode_ids([big], None, max_len=6, kv_cache=True, use_graphs=True)
+    a2 = m.greedy_decode_ids([feats2], None, max_len=30, kv_cache=True, use_graphs=True)
+    assert torch.equal(a2, b)
+    # with a frame mask (static mask copy inside the captured prologue)
+    mask = torch.zeros(4, 12, dtype=torch.bool, device=DEV); mask[1, 9:] = True; mask[3, 5:] = True
+    c1 = m.greedy_decode_ids([feats2], [mask], max_len=30, kv_cache=True, use_graphs=True)
+    c2 = m.greedy_decode_ids([feats2], [mask], max_len=30, kv_cache=True, use_graphs=True)
+    c3 = m.greedy_decode_ids([feats2], [mask], max_len=30, kv_cache=True, use_graphs=False)
+    assert torch.equal(c1, c2) and torch.equal(c1, c3)
 
 
 def test_tiny_decode_stop_rule_with_kv_cache():

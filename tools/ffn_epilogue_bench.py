@@ -35,6 +35,9 @@ def main():
     rows = [("ffn1 plain", lambda: ops.gemm(x, w1, h)),
             ("ffn1 +bias", lambda: ops.gemm(x, w1, h, bias=b1)),
             ("ffn1 +bias+gelu", lambda: ops.gemm(x, w1, h, bias=b1, act="gelu")),
+            ("ffn1 +bias+relu", lambda: ops.gemm(x, w1, h, bias=b1, act="relu")),
+            ("ffn1 +bias+drop", lambda: ops.gemm(x, w1, h, bias=b1, dropout=drop)),
+            ("ffn1 +bias+preact", lambda: ops.gemm(x, w1, h, bias=b1, preact=hpre)),
             ("ffn1 +bias+gelu+preact", lambda: ops.gemm(x, w1, h, bias=b1, act="gelu", preact=hpre)),
             ("ffn1 +bias+gelu+preact+drop", lambda: ops.gemm(x, w1, h, bias=b1, act="gelu", preact=hpre, dropout=drop)),
             ("ffn1 +bias+relu+preact+drop", lambda: ops.gemm(x, w1, h, bias=b1, act="relu", preact=hpre, dropout=drop)),
