@@ -440,6 +440,10 @@ static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
     p.nt_store = env != nullptr ? (env[0] == '1') : (out_bytes > ((size_t)64 << 20));
   }
   {
+    static const char* env = getenv("VCT_GEMM_NT_PREACT");   // A/B switch
+    p.nt_preact = env != nullptr ? (env[0] == '1') : 0;
+  }
+  {
     static const char* env = getenv("VCT_GEMM_ORDER");       // A/B switch: 0 = grouped order always, 1 = short dimension fastest always
     const int ts = pl.tiles_m < pl.tiles_n ? pl.tiles_m : pl.tiles_n;
     p.short_fast = env != nullptr ? (env[0] == '1') : (pl.split > 1 && ts <= 4);

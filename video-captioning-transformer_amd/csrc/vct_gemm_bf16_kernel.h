@@ -387,7 +387,11 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
       }
       if (preact != nullptr) {
-        if ((p.ld_preact % VO) == 0) *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
+        if ((p.ld_preact % VO) == 0) {
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          if (p.nt_preact) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, pv), reinterpret_cast<u32x4*>(preact + (size_t)row * p.ld_preact + col));
+          else *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
+        }
         else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];
       }
     } else {

@@ -25,6 +25,7 @@ struct GemmP {
   int split;            // number of K splits (gridDim.z of the single launch)
   int* counters;        // != nullptr: per-tile arrival counters (zero on entry/exit): single-pass split-K
   int nt_store;         // streaming-size output: non-temporal stores (keeps the operand tiles L2-resident)
+  int nt_preact;        // the saved pre-activation is not read again before the backward: non-temporal stores
   int short_fast;       // tile order: the SHORTER tile dimension runs fastest (tiles sharing a K-long operand slab are neighbours)
 };
 
