@@ -44,6 +44,29 @@ struct G256P {
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
 };
 
+// instruction q (of R * 8 / (64 * NW) per wave) of dma_tile: one 1-KiB global_load_lds of an operand tile
+template <bool MC, int R, int NW>
+__device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext, int k0,
+                                          int wave, int lane, int q) {
+  const int ci = q * NW + wave;
+  const bf16_t* src;
+  if constexpr (!MC) {
+    const int row = ci * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    src = base + (long)min(r0 + row, r_ext - 1) * ld + k0 + c * 8;
+  } else {
+    constexpr int CPRW = R / 8, RPI = 64 / CPRW, NB = R / 16;
+    const int krow = ci * RPI + lane / CPRW;
+    const int pp = lane % CPRW;
+    const int b = (pp >> 1) ^ (krow & (NB - 1));
+    const int col = (b * 2 + (pp & 1)) * 8;
+    const int rlim = ((r_ext + 7) & ~7) - 8;
+    src = base + (long)(k0 + krow) * ld + min(r0 + col, rlim);
+  }
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
+}
+
 constexpr int G256_BM = 256, G256_BN = 256;
 constexpr int G256_STAGE = (G256_BM + G256_BN) * 128;              // bytes per K stage (64-deep): 64 KB
 constexpr int G256_LDS = 2 * G256_STAGE;                           // the epilogue's row slab lives in the stage that was just consumed
@@ -123,10 +146,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the current stage has landed
       __builtin_amdgcn_s_barrier();                          // ... everyone's has; everyone is done with the other buffer
       asm volatile("" ::: "memory");
-      if (!(p.dbg & 2)) {
-        if (kt + 1 < k_hi) issue(m0, n0, kt + 1, buf ^ 1);
-        else if (have_next) issue(m1, n1, k1_lo, buf ^ 1);   // flies under this item's tail + epilogue
-      }
+      // The next stage's operands (this item's, or the first stage of the NEXT item, which then flies under this item's tail and
+      // epilogue).  A full stage goes by DMA, ONE instruction after each row tile's MFMAs of the first k-step: issued back to back
+      // at the top of the step, the 64 wave-instructions of a stage (1 KiB each) queue up behind the CU's vector-memory issue port
+      // and every wave sits in "issue" for the whole transfer before it gets to its fragment reads (K loop 14.1 us per tile with
+      // 7 us of MFMA work in it).  A ragged stage takes the register path up front, as before.
+      const bool nx_own = kt + 1 < k_hi;
+      const int nx_m = nx_own ? m0 : m1, nx_n = nx_own ? n0 : n1, nx_kt = nx_own ? kt + 1 : k1_lo;
+      const bool nx_any = (nx_own || have_next) && !(p.dbg & 2);
+      const bool nx_dma = nx_any && nx_kt < kt_full;
+      if (nx_any && !nx_dma) issue(nx_m, nx_n, nx_kt, buf ^ 1);
+      unsigned char* nb = lds + (buf ^ 1) * G256_STAGE;
       const unsigned char* la = lds + buf * G256_STAGE;
       const unsigned char* lb = la + G256_BM * 128;
       if (!(p.dbg & 1))
@@ -138,9 +168,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) fb[j] = frag2<B_MC, G256_BN, KSPLIT>(lb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++) {
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          if (ks == 0 && nx_dma) {        // (one per TWO row tiles over both k-steps: no better)
+            if (i < TM / 2) dma_piece<A_MC, G256_BM, NW>(nb, p.A, p.lda, nx_m, p.M, nx_kt * BK2, wave, lane, i);
+            else dma_piece<B_MC, G256_BN, NW>(nb + G256_BM * 128, p.B, p.ldb, nx_n, p.N, nx_kt * BK2, wave, lane, i - TM / 2);
+          }
+        }
         if constexpr (BG) {
           if (do_bg) {
 #pragma unroll
@@ -255,12 +290,16 @@ template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hi
 int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split) {
   *used = false;
   *reduce_split = 1;
-  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN, 8 = NT split over K (narrow output).  Default 9: measured on the same box (tools/gemm_bench.py
+  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN, 8 = NT split over K (narrow output).  Default 11 (NT, NN, NT split).
+  // With the DMA instructions spread between the MFMA groups (and their addresses no longer hoisted: no spills in any form) the same
+  // box gives NT 184 vs 250, NN 223 vs 248, TN 182 vs 192 us against the 128x128 kernel; in the STEP the TN form (the weight gradient,
+  // which runs beside the encoder backward on the other stream) makes things worse -- one workgroup per CU with 128 KB of LDS leaves
+  // no room for the co-scheduled kernels: 2.52 vs 2.48 ms -- so it stays off.  History: measured on the same box (tools/gemm_bench.py
   // --auto, cfg-B vocabulary shapes) NT 214 vs 253 us on the 128x128 kernel, but NN 260 vs 249 and TN 222 vs 193 -- the forms
   // whose operands go through the LDS transpose read need twice the fragment reads and spill at 256 VGPRs; they stay available
   // (and tested) behind the mask.
   static const char* env = getenv("VCT_GEMM256");
-  const int mask = env != nullptr ? atoi(env) : 9;
+  const int mask = env != nullptr ? atoi(env) : 11;
   if (mask == 0 || d->dtype != VCT_BF16 || d->reserved != 0) return VCT_OK;
   if (d->act != VCT_ACT_NONE || d->preact || d->addend || d->dact_src || (d->seed && d->p_drop > 0.0f)) return VCT_OK;
   const int form = d->ta * 2 + d->tb;                         // 1 NT, 0 NN, 2 TN
