@@ -14,6 +14,7 @@ import torch
 
 from . import ops
 from .engine import DecodeState, _Buf
+from .utils import capture_graph
 
 
 @torch.no_grad()
@@ -84,7 +85,7 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
                 min_.copy_(mask)
             dec.decode_begin(st, enc.forward(fin, min_, False), pre.start_id, pre.pad_id)      # warm-up: allocates
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):
                 dec.decode_begin(st, enc.forward(fin, min_, False), pre.start_id, pre.pad_id)
             st.begin = {"key": key, "gen": _Buf.generation, "g": g, "fin": fin, "min": min_}
         else:
@@ -114,7 +115,7 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
                 dec.decode_step(st, t, pre.end_id)         # warm-up run (allocates the step's temporaries)
                 # the warm-up already wrote ys[:, t]; capture replays the same work
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with capture_graph(g):
                     dec.decode_step(st, t, pre.end_id)
                 st.graphs[t] = g
             else:

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .utils import capture_graph
 
 
 class GradExchange:
@@ -438,7 +439,7 @@ class CaptionTrainer:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                with capture_graph(graph):
                     loss = self._step_kernels(*static)
             except Exception:                       # capture is an optimisation, never a requirement
                 self.use_graph = False

@@ -55,3 +55,25 @@ def configure_hardware(backend: str = None):
         kw = {"device_id": device} if (use_cuda and backend in (None, "nccl")) else {}
         dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
     return device, rank, world
+
+
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def capture_graph(graph: "torch.cuda.CUDAGraph"):
+    """`with torch.cuda.graph(graph)` with the cyclic garbage collector held off for the duration of the capture.  A collection
+    that happens to run INSIDE a capture destroys whatever unreachable objects it finds -- older CUDAGraphs, pinned host tensors,
+    events of sessions that earlier code dropped -- and their destructors call HIP APIs that are illegal while a stream of this
+    thread is capturing; the error surfaces inside a C++ destructor and aborts the process (seen once in ~4 runs of the GPU test
+    suite, at a different place each time).  torch.cuda.graph collects BEFORE it starts capturing; this keeps it that way."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
