@@ -13,5 +13,5 @@ for f in "$@"; do git -C $root show $rev:video-captioning-transformer_amd/csrc/$
 cd $tmp/pkg/csrc
 objs=""
 for s in *.hip; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -c $s -o ${s%.hip}.o & done; wait
-hipcc --offload-arch=gfx950 -shared -fPIC *.o -o $root/video-captioning-transformer_amd/libvct_hip_ab.so
+hipcc --offload-arch=gfx950 -shared -fPIC *.o -ldl -o $root/video-captioning-transformer_amd/libvct_hip_ab.so
 echo built $root/video-captioning-transformer_amd/libvct_hip_ab.so

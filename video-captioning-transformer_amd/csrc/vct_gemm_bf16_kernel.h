@@ -20,6 +20,13 @@
 //    derivative fused; bias gradient via one extra MFMA against a ones fragment; deterministic
 //    split-K (partials + second pass in vct_gemm.hip).
 #pragma once
+#include <type_traits>
+// Which forms interleave the next K tile's DMA with the MFMAs (see `compute`): the NN form (dX GEMMs) only.  Alone every form gains 0-11 %
+// (tools/gemm_bench.py, same box); in the training step the NT / TN forms LOSE (the TN weight-gradient GEMMs run beside other kernels on
+// the second stream and slow down more than they gain: step 2.54 vs 2.51 ms), the NN form wins (2.47 vs 2.49 ms).
+#ifndef VCT_GEMM_DMA_IL
+#define VCT_GEMM_DMA_IL(TA, TB, BM, BN, NW) ((TA) == 0 && (TB) == 0)
+#endif
 #include "vct_common.h"
 #include "vct_gemm_params.h"
 
@@ -154,6 +161,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
   constexpr bool KSPLIT = A_MC && B_MC;
   constexpr int NW = WGM * WGN, NT = 64 * NW;         // waves / threads per workgroup
+  constexpr bool DMA_IL = VCT_GEMM_DMA_IL(TA, TB, BM, BN, NW);   // interleave the next tile's DMA with this tile's MFMAs
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[NBUF * BUF_BYTES];
@@ -218,7 +226,11 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   // bias-gradient MFMAs sit behind one branch at the END: a branch between the two k-steps (the former shape of this
   // loop) splits the basic block, and hipcc then issues "6 reads, wait for all, 8 MFMAs" twice per tile with the LDS
   // latency of the second group fully exposed.  As one block the k-step-1 reads fly under the k-step-0 MFMAs.
-  auto compute = [&](const unsigned char* la, const unsigned char* lb) {
+  // WITH_DMA: the next K tile (ktn, fully inside K) goes into `nb` by this wave's DMA instructions, placed by the scheduling hints
+  // one at a time BETWEEN the MFMA groups of the first half of this tile (see vct_gemm256.hip: issued back to back, the DMA
+  // instructions of a stage queue up behind the CU's vector-memory port and the wave cannot reach its fragment reads meanwhile).
+  auto compute = [&](const unsigned char* la, const unsigned char* lb, auto WITH_DMA, unsigned char* nb, const int ktn) {
+    constexpr bool DMA = decltype(WITH_DMA)::value;
     constexpr int KS = BK2 / 32;
     bf16x8 fa[KS][TM], fb[KS][TN];
 #pragma unroll
@@ -238,8 +250,22 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
     // waits, so the k-step-0 MFMAs start as soon as their six fragments are back while the k-step-1 reads are in flight);
     // left alone hipcc minimises registers instead: 2-4 reads, wait for all, 2-4 MFMAs, five times per tile
     constexpr int N_DSREAD = KS * (TM * (A_MC ? 2 : 1) + TN * (B_MC ? 2 : 1));
-    __builtin_amdgcn_sched_group_barrier(0x100, N_DSREAD, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN, 0);
+    constexpr int NMF = KS * TM * TN;
+    if constexpr (DMA) {
+      constexpr int NP = BM * 8 / (64 * NW) + BN * 8 / (64 * NW);      // DMA instructions per wave and stage
+      constexpr int GRP = (NMF / 2 / NP) > 0 ? (NMF / 2 / NP) : 1;     // MFMAs between two of them (all inside the first half)
+      dma_tile<A_MC, BM, NW>(nb, A, p.lda, m0, p.M, ktn * BK2, wave, lane);
+      dma_tile<B_MC, BN, NW>(nb + A_BYTES, B, p.ldb, n0, p.N, ktn * BK2, wave, lane);
+      __builtin_amdgcn_sched_group_barrier(0x100, N_DSREAD, 0);
+      static_for<NP>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      });
+      if constexpr (NMF - NP * GRP > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NP * GRP, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, N_DSREAD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+    }
     if constexpr (BG) {
       if (do_bias_grad) {
 #pragma unroll
@@ -271,16 +297,26 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       if (kt > kt_begin) __syncthreads();             // everyone finished reading the buffer
       stage(kt, 0);
       __syncthreads();                                // DMA landed (vmcnt(0)) for everyone
-      compute(lds_raw, lds_raw + A_BYTES);
+      compute(lds_raw, lds_raw + A_BYTES, std::false_type{}, nullptr, 0);
     }
   } else {
     static_assert(NBUF == 2, "NBUF is 1 or 2");
     if (kt_begin < kt_end) stage(kt_begin, 0);
     int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; kt++) {
+    int kt = kt_begin;
+    if constexpr (DMA_IL) {
+      // hot loop: the next tile is a full one -> its DMA rides between this tile's MFMAs; one basic block per K tile
+      for (; kt + 1 < kt_full_end; kt++) {
+        __syncthreads();
+        const unsigned char* la = lds_raw + cur * BUF_BYTES;
+        compute(la, la + A_BYTES, std::true_type{}, lds_raw + (cur ^ 1) * BUF_BYTES, kt + 1);
+        cur ^= 1;
+      }
+    }
+    for (; kt < kt_end; kt++) {                       // (DMA_IL: the last one or two tiles; ragged next tile by the register path)
       __syncthreads();
       if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
-      compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES);
+      compute(lds_raw + cur * BUF_BYTES, lds_raw + cur * BUF_BYTES + A_BYTES, std::false_type{}, nullptr, 0);
       cur ^= 1;
     }
   }
