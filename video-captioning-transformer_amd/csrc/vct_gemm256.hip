@@ -364,6 +364,11 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
     if ((int64_t)p.split * d->M * d->N * 4 > d->workspace_bytes) return VCT_OK;
     p.partial = reinterpret_cast<float*>(d->workspace);
     p.nt_store = 0;
+    {   // K split outermost, N fastest inside: the two N tiles that stream the same 2.6 MB slab of dlogits are neighbours on one XCD
+      static const char* zenv = getenv("VCT_GEMM256_ZMAJOR");
+      p.zmajor = zenv != nullptr ? (zenv[0] == '1') : 1;
+      if (p.zmajor) p.order = 1;
+    }
     const int rc = g256_launch<0, 0, float>(p, st);          // TO = float: the slab / partial element type
     if (rc == VCT_OK) { *used = true; *reduce_split = p.split; }
     return rc;
