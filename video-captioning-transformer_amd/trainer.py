@@ -6,6 +6,7 @@ all-reduce of the flat gradient buffer over RCCL (torch.distributed 'nccl' on RO
 bucket as soon as the backward schedule has enqueued the kernels that complete it, so the exchange
 of the generator gradients (a third of the bytes, ready first) overlaps the rest of backward."""
 from typing import List, Optional
+import os
 
 import torch
 import torch.distributed as dist
@@ -321,6 +322,9 @@ class CaptionTrainer:
         # Adam always runs per bucket as each all-reduce lands (it overlaps the wire, not the GEMMs)
         self.overlap_adam = False
 
+    # A/B switch (single GPU): the whole Adam pass after the joined backward instead of 86 % of it beside the encoder backward
+    adam_after_backward = os.environ.get("VCT_ADAM_TAIL", "0") == "1"
+
     def _step_kernels(self, feats, mask, ids):
         m = self.model
         fused = isinstance(self.opt, FusedAdam)
@@ -361,7 +365,7 @@ class CaptionTrainer:
             if _StackBase._side is not None:
                 ops.stream_wait(None, _StackBase._side)
             self.opt.finish_ranges()
-        elif fused and feats.is_cuda and m.overlap_enc_bwd:
+        elif fused and feats.is_cuda and m.overlap_enc_bwd and not self.adam_after_backward:
             # the encoder backward is still running on the side stream when the decoder's tail is done: Adam on everything
             # but the encoder (86 % of the parameters at cfg-B) fills that gap on the main stream, the rest follows the join
             loss = m.train_step_kernels(feats, mask, ids, defer_join=True)
