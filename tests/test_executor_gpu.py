@@ -196,3 +196,14 @@ def test_rccl_bf16_payload_world1_is_close_to_the_fp32_step():
     e = m.caption_param_end
     assert float((m.flat_params[:e] - ref[:e]).abs().max()) < 5e-3      # Adam normalises: a bf16-rounded gradient moves a weight <= 2 lr
     coll.close()
+
+
+@pytest.mark.parametrize("executor", ["eager", "list"])
+def test_adam_after_the_joined_backward_is_the_same_step(executor, monkeypatch):
+    """A/B switch CaptionTrainer.adam_after_backward: the whole Adam pass behind the joined backward instead of most of it beside the
+    encoder backward -- a different stream schedule of the same kernels: parameters and losses must be bitwise equal."""
+    from vct_amd.trainer import CaptionTrainer
+    p0, l0, _ = _run(executor)
+    monkeypatch.setattr(CaptionTrainer, "adam_after_backward", True)
+    p1, l1, _ = _run(executor)
+    assert torch.equal(l0, l1) and torch.equal(p0, p1)
