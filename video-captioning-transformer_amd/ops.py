@@ -86,7 +86,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
     lib = L.load()
     d = _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
                    n_valid, k_valid, m_valid)
-    timed = _taps_on and tag in TAPS
+    timed = _taps_on and tag in TAPS and (_taps_only is None or tag in _taps_only)
     if timed:
         tap(tag, 0)
     L.check(lib.vct_gemm(d, L.stream_ptr()), "vct_gemm")
@@ -429,17 +429,23 @@ def masked_stream(cu_bits, device=None):
 
 TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6}
 _taps_on = False
+_taps_only = None        # None = every tag, else the set of tags that are bracketed
 
 
-def taps_enable(on: bool):
-    global _taps_on
+def taps_enable(on: bool, only=None):
+    """Switch the live timing brackets on / off; `only`: an iterable of tags to restrict them to.  Every bracket is two HIP event
+    records in the step's stream -- seven brackets cost the cfg-B step ~55 us (tools/taps_cost.py) -- so a benchmark keeps only the
+    one it needs inside its timed region.  Recorded launch lists / graphs contain the brackets that were active when they were
+    made: drop them (CaptionTrainer.drop_recordings) after changing this."""
+    global _taps_on, _taps_only
     _taps_on = bool(on)
+    _taps_only = None if only is None else frozenset(only)
     L.check(L.load().vct_tap_enable(int(_taps_on)), "vct_tap_enable")
 
 
 def tap(tag: str, phase: int, stream=None):
     """Bracket a region of `stream` with HIP timing events (phase 0 = start, 1 = end); no-op while taps are disabled."""
-    if _taps_on:
+    if _taps_on and (_taps_only is None or tag in _taps_only):
         L.check(L.load().vct_tap(TAPS[tag], phase, _sptr(stream)), "vct_tap")
 
 

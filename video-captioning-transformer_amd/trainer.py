@@ -389,6 +389,12 @@ class CaptionTrainer:
         ops.tap("step", 1)
         return loss
 
+    def drop_recordings(self):
+        """Forget every recorded launch list / captured graph (they are re-made on the next step of each shape): needed after
+        anything that changes WHAT a step launches, e.g. ops.taps_enable(...)."""
+        self._lists.clear()
+        self._graphs.clear()
+
     def _static_inputs(self, key, feats, mask, ids):
         st = getattr(self, "_static", None)
         if st is None:
