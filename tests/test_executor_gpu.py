@@ -207,3 +207,22 @@ def test_adam_after_the_joined_backward_is_the_same_step(executor, monkeypatch):
     monkeypatch.setattr(CaptionTrainer, "adam_after_backward", True)
     p1, l1, _ = _run(executor)
     assert torch.equal(l0, l1) and torch.equal(p0, p1)
+
+
+def test_adopted_input_buffers_skip_the_staging_copies_and_give_the_same_step():
+    """CaptionTrainer.adopt_inputs: a producer that writes its batches into the executor's own static buffers; same losses and
+    parameters as passing fresh tensors (which step() copies into those buffers)."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    p0, l0, _ = _run("list", steps=4)
+    m = _model()
+    m._seed.fill_(1234)
+    opt = FusedAdam(m, lr=1e-3)
+    tr = CaptionTrainer(m, opt, launch_list=True)
+    f, k, i = tr.adopt_inputs(*_batch(100))
+    losses = []
+    for s in range(4):
+        nf, nk, ni = _batch(100 + s)
+        f.copy_(nf); k.copy_(nk); i.copy_(ni)               # the producer fills the adopted buffers in place
+        losses.append(tr.step(f, k, i).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(losses), l0) and torch.equal(m.flat_params, p0)

@@ -403,11 +403,27 @@ class CaptionTrainer:
         if s is None:
             s = st[key] = (feats.clone(), None if mask is None else mask.clone(), ids.clone())
         else:
-            s[0].copy_(feats, non_blocking=True)
-            if mask is not None:
+            # a caller that already works in the static buffers (adopt_inputs) skips the staging copies: three small device copies
+            # and the launch gaps around them are ~35 us at the head of a 2.4 ms step
+            if s[0].data_ptr() != feats.data_ptr():
+                s[0].copy_(feats, non_blocking=True)
+            if mask is not None and s[1].data_ptr() != mask.data_ptr():
                 s[1].copy_(mask, non_blocking=True)
-            s[2].copy_(ids, non_blocking=True)
+            if s[2].data_ptr() != ids.data_ptr():
+                s[2].copy_(ids, non_blocking=True)
         return s
+
+    def _input_key(self, feats, mask, ids):
+        return (tuple(feats.shape), feats.dtype, None if mask is None else tuple(mask.shape), tuple(ids.shape), self.model.training)
+
+    def adopt_inputs(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor):
+        """The trainer's own static input buffers for this shape, initialised with the given batch.  Recorded launch lists and
+        captured graphs read their inputs from these buffers, so step() normally copies every batch into them; a producer that
+        writes its batches INTO them (a device-side loader, a benchmark with resident data) and passes them to step() has no copy
+        left.  Returns (feats, mask, ids) views of the buffers; without a recording executor the inputs are returned unchanged."""
+        if not (self.use_graph or self.use_list):
+            return feats, mask, ids
+        return self._static_inputs(self._input_key(feats, mask, ids), feats, mask, ids)
 
     def step(self, feats: torch.Tensor, mask: Optional[torch.Tensor], ids: torch.Tensor) -> torch.Tensor:
         """Returns this rank's loss as a device tensor [1] (no host sync)."""
@@ -420,7 +436,7 @@ class CaptionTrainer:
             self._graphs.clear()
             self._lists.clear()
             self._gen = _Buf.generation
-        key = (tuple(feats.shape), feats.dtype, None if mask is None else tuple(mask.shape), tuple(ids.shape), self.model.training)
+        key = self._input_key(feats, mask, ids)
         static = self._static_inputs(key, feats, mask, ids)
         if self.use_list:
             ll = self._lists.get(key)
