@@ -137,6 +137,18 @@ def test_taps_time_kernels_inside_replays():
         ops.taps_enable(False)
     assert len(ms) == 4 and all(0.0 < x < 1000.0 for x in ms)
     assert len(gen) == 4 and all(0.0 < x <= y for x, y in zip(gen, ms))
+    # a restricted bracket set (what bench.py keeps inside its timed region); recordings made under another set are dropped
+    for tag in ops.TAPS:
+        ops.tap_collect(tag)                                  # drain the brackets of the first phase
+    ops.taps_enable(True, only=("gen_fwd",))
+    try:
+        tr.drop_recordings()
+        for k in range(3):
+            tr.step(*_batch(5))
+        torch.cuda.synchronize()
+        assert len(ops.tap_collect("gen_fwd")) == 3 and ops.tap_collect("step") == [] and ops.tap_collect("adam") == []
+    finally:
+        ops.taps_enable(False)
 
 
 def test_fused_attention_block_in_the_training_step(monkeypatch):
