@@ -238,3 +238,28 @@ def test_adopted_input_buffers_skip_the_staging_copies_and_give_the_same_step():
         losses.append(tr.step(f, k, i).clone())
     torch.cuda.synchronize()
     assert torch.equal(torch.cat(losses), l0) and torch.equal(m.flat_params, p0)
+
+
+def test_vocabulary_dx_through_the_maintained_transposed_shadow(monkeypatch):
+    """DecoderEngine.gen_dx_nt: dX = dlogits W_g in the NT form reads W_g^T, which ParamSet keeps beside the bf16 shadow (rewritten
+    behind every optimizer pass over W_g).  Same training trajectory as the NN form up to bf16 GEMM rounding, and W_g^T equals the
+    shadow's transpose after every step (eager and recorded)."""
+    from vct_amd.engine import DecoderEngine
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    p0, l0, _ = _run("list", steps=4)
+    monkeypatch.setattr(DecoderEngine, "gen_dx_nt", True)
+    for executor in ("eager", "list"):
+        m = _model()
+        m._seed.fill_(1234)
+        tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), launch_list=executor == "list")
+        losses = [tr.step(*_batch(100 + k)).clone() for k in range(4)]
+        torch.cuda.synchronize()
+        ps = m._ps
+        name = "cap_decoder.generator.weight"
+        assert name in ps.transposed
+        t = ps.transposed[name][0]
+        w = ps.c[name]
+        assert torch.equal(t[:, :w.shape[0]], w.t())
+        l1 = torch.cat(losses)
+        assert float((l1 - l0).abs().max()) < 2e-2 * float(l0.abs().max())
+        assert float((m.flat_params - p0).abs().max()) < 5e-3

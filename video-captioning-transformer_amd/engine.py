@@ -16,13 +16,14 @@ Data layout in HBM (row-major, tokens x features):
 """
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
 
 ENC_SITE, DEC_SITE, EMB_SITE = 0, 1000, 999
 DMEM_SYNC = 0      # named sync point (ops.sync_record / sync_wait): d(memory) is final on the main stream
-WGT_SYNC = 1       # the transposed shadow of the generator weight is ready (side stream)
 
 
 class ParamSet:
@@ -57,6 +58,9 @@ class ParamSet:
             self.cflat = torch.zeros(self.total, dtype=compute_dtype, device=device)
             self.c = {n: self.cflat[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape) for n, p in named}
         self._stamp = None
+        # transposed copies of individual weight matrices in the compute dtype (name -> (tensor [cols, ld], start, end)): kept in
+        # step with the shadow by refresh_shadow / cast_range / FusedAdam.step_range (refresh_transposed)
+        self.transposed = {}
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
         self.cast_ranges, start = [], 0
         for n in self.names:
@@ -86,6 +90,7 @@ class ParamSet:
                 return
         for a, b in self.cast_ranges:
             ops.cast(self.flat[a:b], self.cflat[a:b])
+        self.refresh_transposed(0, self.total)
         self._stamp = stamp if stamp is not None else sum(p._version for p in self.params.values())
 
     def cast_range(self, a: int, b: int):
@@ -96,6 +101,25 @@ class ParamSet:
             lo, hi = max(a, x), min(b, y)
             if hi > lo:
                 ops.cast(self.flat[lo:hi], self.cflat[lo:hi])
+        self.refresh_transposed(a, b)
+
+    def want_transposed(self, name: str) -> torch.Tensor:
+        """A [cols, ld >= rows] transposed copy (compute dtype) of the 2-D weight `name`, created on first use and from then on
+        rewritten whenever the shadow of that weight is (the whole matrix must lie inside the refreshed range)."""
+        ent = self.transposed.get(name)
+        if ent is None:
+            w = self.c[name]
+            rows, cols = w.shape
+            t = torch.zeros(cols, (rows + 31) // 32 * 32, dtype=w.dtype, device=w.device)
+            a = self.offsets[name]
+            ent = self.transposed[name] = (t, a, a + w.numel())
+            ops.transpose(w, t)
+        return ent[0]
+
+    def refresh_transposed(self, a: int, b: int):
+        for name, (t, x, y) in self.transposed.items():
+            if a <= x and y <= b:
+                ops.transpose(self.c[name], t)
 
     def install_grads(self):
         for n, p in self.params.items():
@@ -563,16 +587,10 @@ class DecoderEngine(_StackBase):
         b.t["kpm"] = kpm
         self._wgt = None
         if training and self.gen_dx_nt and self.dt == torch.bfloat16 and self.dev.type == "cuda":
-            # dX = dlogits W_g runs ~25 % faster in the K-contiguous NT form on the persistent 256x256 kernel than in the NN form
-            # (LDS transpose reads): keep a transposed shadow [d, Vp] of this step's W_g, written on the side stream under the
-            # layer stack (62 MB of HBM traffic beside L2-bound kernels); the backward waits for it by event
-            wgt = b.get("wg_t", (self.cfg["d"], self.Vp), self.dt)
-
-            def tr(_ws):
-                ops.transpose(self.W("generator.weight"), wgt)
-                ops.sync_record(WGT_SYNC)
-            self._on_side(tr)
-            self._wgt = wgt
+            # dX = dlogits W_g in the K-contiguous NT form (persistent 256x256 kernel, split over K): needs W_g^T, which the
+            # parameter set keeps beside the bf16 shadow -- rewritten right after the optimizer has touched W_g (62 MB of traffic
+            # in the main stream's slack at the end of the step), not here in front of the latency-bound layer stack
+            self._wgt = self.ps.want_transposed(self.pre + "generator.weight")
         y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
         ops.tap("layers_fwd", 1)
         logits = b.get("logits", (M, self.Vp), self.dt)
@@ -611,7 +629,6 @@ class DecoderEngine(_StackBase):
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
         if getattr(self, "_wgt", None) is not None:
-            ops.sync_wait(WGT_SYNC)
             ops.gemm(dl, self._wgt, dy, ta=False, tb=True, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
         else:
             ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
@@ -873,10 +890,12 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
     return _decoder_decode_step(self, st, t, end_id)
 
 
-# A/B switch: vocabulary dX through a transposed weight shadow (NT form on the persistent 256x256 kernel, split over K).  Measured
-# in the step (same box, tools/ab_dx.sh): the dX bracket drops 0.214 -> 0.181 ms, but the 62 MB transpose (35 us alone) beside the
-# latency-bound layer stack costs the forward 0.605 -> 0.66 ms: no net gain (2.53 vs 2.52 ms), so it stays off.
-DecoderEngine.gen_dx_nt = False
+# A/B switch: vocabulary dX through a transposed weight shadow (NT form on the persistent 256x256 kernel, split over K).  The shadow is
+# maintained by the parameter set (ParamSet.want_transposed): one 35 us transpose behind the optimizer's pass over W_g, in the main
+# stream's slack at the end of the step.  (Rebuilt in front of the layer stack at every step it cost the forward more than the dX
+# gained.)  Measured in the step (same box): the dX bracket drops 0.218 -> 0.181 ms and the Adam bracket grows by the 40 us of the
+# transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
+DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "0") == "1"
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 

@@ -227,6 +227,8 @@ class FusedAdam(torch.optim.Optimizer):
         s0, s1 = max(self.skip[0], a) - a, min(self.skip[1], b) - a
         ops.adam_step(ps.flat[a:b], ps.gflat[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], shadow, lr, b1, b2, eps, wd,
                       self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper)
+        if shadow is not None:
+            ps.refresh_transposed(a, b)          # transposed weight copies follow the shadow this kernel has just rewritten
 
     @torch.no_grad()
     def finish_ranges(self):
