@@ -213,7 +213,17 @@ __global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const in
   float s = 0.0f;
   if (c < 2 * d) {
     const int which = c / d, col = c % d;
-    for (int r = rg; r < nws; r += 16) s += ws[((size_t)r * 2 + which) * d + col];
+    // eight loads in flight per thread (the adds keep their order): the ~38 partial rows of a thread were a chain of L2 round trips
+    const float* src = ws + (size_t)which * d + col;
+    int r = rg;
+    for (; r + 7 * 16 < nws; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = src[(size_t)(r + u * 16) * 2 * d];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; r < nws; r += 16) s += src[(size_t)r * 2 * d];
   }
   red[rg][cx] = s;
   __syncthreads();
