@@ -362,6 +362,16 @@ int vct_cmdlist_end(void* list);
 int vct_cmdlist_replay(void* list, void* main_stream);
 int vct_cmdlist_size(void* list);     /* recorded commands */
 int vct_cmdlist_streams(void* list);  /* distinct streams seen while recording */
+/* A replayed command cannot hand a status back to the call that recorded it: the FIRST non-zero status any command of a
+ * replay produces (a failed RCCL collective: ncclResult_t + 10000; a failed event record / wait / memset: hipError_t) is
+ * kept and returned by that vct_cmdlist_replay.  vct_cmdlist_inject_status is the fault-injection hook of that path:
+ * eager it returns `status`; while recording it appends a command on `stream` that reports `status` at every replay. */
+int vct_cmdlist_inject_status(int status, void* stream);
+/* Host work in launch order: fn(arg) runs on the calling host thread after everything enqueued on `stream` so far has
+ * FINISHED (the stream is synchronised first) -- now, or at that point of every replay while recording.  A non-zero return
+ * of fn is reported like any other command status.  For collectives that are host calls (gloo / torch.distributed in the
+ * one-GPU multi-rank tests); RCCL collectives (vct_comm_*) are stream work and never need it. */
+int vct_cmdlist_host_call(int (*fn)(void*), void* arg, void* stream);
 /* Cross-stream ordering, recordable: `waiter` will not run work enqueued after this call before everything enqueued on
  * `signal` so far has finished (event record + stream wait; replaces torch's Stream.wait_stream on the fast path). */
 int vct_stream_wait(void* waiter_stream, void* signal_stream);

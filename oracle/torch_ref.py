@@ -122,7 +122,8 @@ class RefCaptionModel(nn.Module):
 
 
 def time_training_steps(cfg, dropout, feats, mask, ids, steps, threads, lr=1e-4):
-    """samples/s of `steps` timed steps (after one warm-up) of forward + zero_grad + backward + Adam (train.py:119-131)."""
+    """samples/s at the MEDIAN of `steps` timed steps (after one warm-up) of forward + zero_grad + backward + Adam
+    (train.py:119-131; BASELINE.md section 3: >= 5 timed steps, median).  Returns (rate, seconds spent in timed steps, loss)."""
     import time
     torch.set_num_threads(threads)
     torch.manual_seed(666)
@@ -130,7 +131,7 @@ def time_training_steps(cfg, dropout, feats, mask, ids, steps, threads, lr=1e-4)
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=lr, betas=(0.9, 0.999))
     f, mk, i = torch.from_numpy(feats), torch.from_numpy(mask), torch.from_numpy(ids)
-    total, n, loss = 0.0, 0, None
+    times, loss = [], None
     for it in range(steps + 1):
         t0 = time.perf_counter()
         _, loss = m(f, mk, i)
@@ -139,6 +140,7 @@ def time_training_steps(cfg, dropout, feats, mask, ids, steps, threads, lr=1e-4)
         opt.step()
         dt = time.perf_counter() - t0
         if it > 0:
-            total += dt
-            n += 1
-    return feats.shape[0] * n / total, total, float(loss)
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return feats.shape[0] / med, sum(times), float(loss)

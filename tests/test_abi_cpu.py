@@ -120,3 +120,27 @@ def test_runtime_entry_points_validate_arguments(lib_path):
     assert lib.vct_tap(16, 0, None) == -1 and lib.vct_tap(0, 2, None) == -1
     assert lib.vct_tap(0, 0, None) == 0                      # taps disabled: no-op
     assert lib.vct_tap_collect(0, None, 0) == 0
+
+
+def test_replay_reports_the_first_failed_command(lib_path):
+    """A command of a recorded list cannot return a status to the call that recorded it: the first non-zero status of a replay
+    (failed RCCL collective, event record / wait, memset) must come back from vct_cmdlist_replay.  vct_cmdlist_inject_status is
+    the fault-injection hook of that path (host commands, which need a device to drain a stream: tests/test_executor_gpu.py)."""
+    from vct_amd import _lib
+    lib = _lib.load()
+    assert lib.vct_cmdlist_inject_status(0, None) == 0 and lib.vct_cmdlist_inject_status(10005, None) == 10005      # eager
+    assert lib.vct_cmdlist_host_call(None, None, None) == -1
+    h = ctypes.c_void_p()
+    assert lib.vct_cmdlist_create(ctypes.byref(h)) == 0
+    assert lib.vct_cmdlist_begin(h, None) == 0
+    assert lib.vct_cmdlist_inject_status(0, None) == 0
+    assert lib.vct_cmdlist_inject_status(10003, None) == 0        # recorded, not reported now
+    assert lib.vct_cmdlist_inject_status(10007, None) == 0
+    assert lib.vct_cmdlist_end(h) == 0
+    assert lib.vct_cmdlist_size(h) == 3
+    assert lib.vct_cmdlist_replay(h, None) == 10003               # the FIRST failure, sticky over the rest of the replay
+    with pytest.raises(RuntimeError, match="ncclResult_t 3"):
+        _lib.check(lib.vct_cmdlist_replay(h, None), "replay")
+    assert lib.vct_cmdlist_begin(h, None) == 0 and lib.vct_cmdlist_end(h) == 0
+    assert lib.vct_cmdlist_replay(h, None) == 0                   # a fresh (empty) recording: no stale status
+    assert lib.vct_cmdlist_destroy(h) == 0

@@ -178,3 +178,82 @@ def test_cfgB_greedy_decode_batch128_vs_oracle():
     assert ys.shape == ref_ys.shape
     n = _compare_until_margin(ys, ref_ys, margins, 5e-5)
     assert n > 0.9 * ref_ys.size
+
+
+@pytest.mark.parametrize("B", [1, 16, 128])
+def test_cfgB_bf16_kv_cache_step_teacher_forced(B):
+    """The bf16 token step that bench.py times -- batch 1: weight-streaming matrix-vector kernels (vct_decode_gemv), batch >= 2:
+    skinny MFMA projections with LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
+    caption: the predicted next id must be the reference's wherever its top-2 logit margin is resolvable in bf16 (> 0.15),
+    over >= 9 positions.  Batch 1 / 16: ids and margins recorded from the reference (cfgB_decode.npz); batch 128: the oracle."""
+    from vct_amd import decode, engine
+    z = load_golden("cfgB_decode.npz")
+    mc, V = model_config_of(z), int(z["vocab"])
+    cfg = O.cfg_from_model_config(mc, V)
+    steps = 10
+    if B in (1, 16):
+        p = O.init_params(cfg, seed=int(z["param_seed"]))
+        f = O.synthetic_batch(B, 12, 512, 20, V, seed=int(z[f"feats_seed_b{B}"]))[0]
+        ref_ys, margins = z[f"ys_b{B}"], z[f"margins_b{B}"]
+    else:
+        p = O.init_params(cfg, seed=778)
+        f = O.synthetic_batch(B, 12, 512, 20, V, seed=21)[0]
+        ref_ys, margins = O.greedy_decode_ids(p, cfg, f, None, max_len=steps + 1, return_margins=True)
+    assert ref_ys.shape[1] >= steps + 1
+    mb = build_model(mc, V, DEV, torch.bfloat16, p)
+    mb.eval()
+    dec = mb.cap_decoder._engine()
+    st = engine.DecodeState(dec, B, 13, steps + 1)
+    if B == 1:
+        assert engine._decoder_small_decode_ok(dec, st)            # the path under test is the one that runs
+    else:
+        assert engine._decoder_fused_decode_ok(dec, st) and not engine._decoder_small_decode_ok(dec, st)
+    feats = torch.from_numpy(f).to(DEV)
+    ref = torch.from_numpy(np.ascontiguousarray(ref_ys[:, :steps + 1])).to(DEV)
+    nxt, lgb = decode.teacher_forced_next_ids(mb, feats, None, ref, steps, return_logits=True)
+    nxt = nxt.cpu().numpy()
+    ok = margins[:, :steps] > 0.15
+    assert ok.sum() >= 0.25 * ok.size and ok[:, :9].any(axis=0).sum() >= (9 if B > 1 else 4)
+    assert np.array_equal(nxt[ok], ref_ys[:, 1:steps + 1][ok]), (nxt[ok] != ref_ys[:, 1:steps + 1][ok]).sum()
+    if B <= 16:
+        # every position, not only the clear-margin ones: the step's logits against the oracle's decode_word (bf16 tolerance)
+        mem = O.mm_encoder_forward(p, cfg, f, None)[0]
+        nb = min(B, 4)
+        for t in range(1, steps + 1):
+            want = O.decode_word(p, cfg, mem[:nb], ref_ys[:nb, :t])
+            assert rel(lgb[:nb, t - 1], want) < 3e-2, (t, rel(lgb[:nb, t - 1], want))
+    # the same step in fp32 (general kernels, exact-fp32 MFMA) agrees everywhere the margin is above fp32 resolution
+    m32 = build_model(mc, V, DEV, torch.float32, p)
+    m32.eval()
+    nxt32, lg32 = decode.teacher_forced_next_ids(m32, feats, None, ref, steps, return_logits=True)
+    ok32 = margins[:, :steps] > 5e-5
+    assert np.array_equal(nxt32.cpu().numpy()[ok32], ref_ys[:, 1:steps + 1][ok32])
+    if B <= 16:
+        assert rel(lg32[:1, steps - 1], O.decode_word(p, cfg, mem[:1], ref_ys[:1, :steps])) < 1e-4
+
+
+def test_shipped_width_fp32_batch1_decode_takes_the_batched_step():
+    """d = 768 in fp32 is 3 sixteen-byte chunks per lane -- not a shape vct_decode_gemv has (1, 2, 4, 8): batch-1 decode (a
+    ragged last eval batch, predict_video.py) must fall back to the batched step instead of raising, and still return the
+    oracle's ids."""
+    from vct_amd import engine
+    mc = {"modal": ["clip"], "modal_shape": [512], "text_enc_type": "CLIP", "embed_dim": 768, "dropout": 0.3, "loss_beta": 0.5,
+          "matching": None, "activation": "gelu",
+          "video_encoder": {"layer": 1, "nhead": 8, "feedforward": 2048,
+                            "mme": {"temporal": "encoding", "modal_different": True, "do_norm": False, "aggregation": "avg"}},
+          "caption_decoder": {"layer": 3, "nhead": 8, "feedforward": 2048, "sce_loss_alpha": 0.5}, "pretrained_model": None}
+    V = 1009
+    cfg = O.cfg_from_model_config(mc, V)
+    p = O.init_params(cfg, seed=5)
+    f = O.synthetic_batch(1, 12, 512, 20, V, seed=3)[0]
+    ref_ys, margins = O.greedy_decode_ids(p, cfg, f, None, max_len=8, return_margins=True)
+    for dtype in (torch.float32, torch.bfloat16):
+        m = build_model(mc, V, DEV, dtype, p)
+        dec = m.cap_decoder._engine()
+        st = engine.DecodeState(dec, 1, 13, 8)
+        assert not engine._decoder_small_decode_ok(dec, st)        # (bf16: 768 = 1.5 x 512 is no whole chunk count either)
+        ys = m.greedy_decode_ids([torch.from_numpy(f).to(DEV)], None, max_len=8).cpu().numpy()
+        if dtype == torch.float32:
+            _compare_until_margin(ys, ref_ys, margins, 5e-5)
+        else:
+            _compare_until_margin(ys, ref_ys, margins, 0.15)

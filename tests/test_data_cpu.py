@@ -217,3 +217,35 @@ def test_weight_file_and_training_state_round_trip(tmp_path):
     assert _same_params(m3, m1)
     with pytest.raises(ValueError):
         ck.load_training_state(str(tmp_path / "w.pth"), m3)       # a bare weight file is not a training state
+
+
+def test_training_state_with_numpy_scalars_loads_again(tmp_path):
+    """Validation losses usually arrive as numpy scalars (np.mean of per-batch losses): EarlyStopping.best_score and
+    ReduceLROnPlateau.best then hold np.float64, which torch.save pickles happily and a weights_only load refuses.  The file
+    must be readable: scalars are stored as plain Python numbers."""
+    from vct_amd import checkpoint as ck
+    from vct_amd.trainer import build_optimizer
+    mc = {"modal": ["x"], "modal_shape": [24], "text_enc_type": "CLIP", "embed_dim": 32, "dropout": 0.1, "loss_beta": 0.5,
+          "matching": {"enable_tem": False, "matching_loss": "CSL"}, "activation": "gelu",
+          "video_encoder": {"layer": 1, "nhead": 4, "feedforward": 48,
+                            "mme": {"temporal": "encoding", "modal_different": True, "do_norm": False, "aggregation": "avg"}, "aoa": False},
+          "caption_decoder": {"layer": 1, "nhead": 4, "feedforward": 48, "sce_loss_alpha": 0.5}, "pretrained_model": None}
+    tc = {"optimizer": {"name": "adam", "learning_rate": 1e-3, "beta": [0.9, 0.999], "weight_decay": 0,
+                        "lr_scheduler": {"name": "ReduceLROnPlateau", "patience": 2}}}
+    m = build_model(mc, 97, "cpu", torch.float32)
+    opt, sch = build_optimizer(tc, m)
+    es = ck.EarlyStopping(patience=3)
+    for v in (np.float64(2.25), np.mean([2.0, 3.0]), np.float32(2.75)):
+        sch.step(v)
+        es(v, m, do_save=False)
+    assert isinstance(es.best_score, np.floating)        # the hazard is real: utils.py:38 keeps whatever type it was given
+    path = str(tmp_path / "s.pt")
+    ck.save_training_state(path, m, opt, sch, epoch=0, early_stopping=es, extra={"val": np.float64(1.5), "n": np.int64(7)})
+    m2 = build_model(mc, 97, "cpu", torch.float32)
+    opt2, sch2 = build_optimizer(tc, m2)
+    es2 = ck.EarlyStopping(patience=3)
+    info = ck.load_training_state(path, m2, opt2, sch2, es2)
+    assert info["extra"] == {"val": 1.5, "n": 7} and type(info["extra"]["val"]) is float
+    assert sch2.best == 2.25 and sch2.num_bad_epochs == sch.num_bad_epochs
+    # (val_loss_min holds the NEGATED value: the reference's own bookkeeping, utils.py:38-47)
+    assert (es2.counter, es2.best_score, es2.val_loss_min) == (es.counter, -2.25, float(es.val_loss_min)) and type(es2.best_score) is float

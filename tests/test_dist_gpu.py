@@ -33,7 +33,35 @@ def _batch(seed, dev):
     return feats, mask.to(dev), ids.to(dev)
 
 
-def _worker(rank, world, port, dtype_name, q, sharded=False):
+def _np_batch(seed):
+    f, mk, i = _batch(seed, "cpu")
+    return f.numpy(), mk.numpy(), i.numpy()
+
+
+def _oracle_mean_step(start_sd, ps, world, steps, lr):
+    """The CHECKER: per step, the CPU oracle's gradient of every rank's batch, averaged over the ranks (what DDP's reducer
+    produces, reference train.py:217-219), then the oracle's Adam (train.py:24-26,126).  Returns (flat mean gradient of the
+    first step laid out like the model's flat buffer, parameters after `steps` steps, |mean gradient| > 1e-5 mask per name)."""
+    import numpy as np
+    import vct_oracle as O
+    cfg = O.cfg_from_model_config(MC, VOCAB)
+    p = {k: v.detach().cpu().numpy().copy() for k, v in start_sd.items()}
+    state, flat1, big = {}, None, None
+    for k in range(steps):
+        gs = [O.caption_loss_and_grads(p, cfg, *_np_batch(10 + rr + 2 * k))[1] for rr in range(world)]
+        g = {n: sum(x[n].astype(np.float64) for x in gs) / world for n in gs[0]}
+        if k == 0:
+            flat1 = np.zeros(ps.total, np.float64)
+            for n, v in g.items():
+                flat1[ps.offsets[n]:ps.offsets[n] + v.size] = v.reshape(-1)
+            big = {n: np.abs(v) > 1e-5 for n, v in g.items()}
+        else:
+            big = {n: big[n] & (np.abs(v) > 1e-5) for n, v in g.items()}
+        p = O.adam_step(p, {n: v.astype(np.float32) for n, v in g.items()}, state, lr=lr)
+    return flat1, p, big
+
+
+def _worker(rank, world, port, dtype_name, q, sharded=False, executor="eager", check_oracle=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -57,10 +85,44 @@ def _worker(rank, world, port, dtype_name, q, sharded=False):
         assert ex.shard_of(0) is not None and ex.shard_of(0)[2] * world == ex.buckets[0][1] - ex.buckets[0][0]
     else:
         ex = GradExchange(m)
-    tr = CaptionTrainer(m, opt, ex)
+    tr = CaptionTrainer(m, opt, ex, launch_list=(executor == "list"))
+    assert tr.use_list == (executor == "list")
     start = m.flat_params.clone()
-    losses = [float(tr.step(*_batch(10 + rank + 2 * k, dev))) for k in range(2)]
+    start_sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    nsteps = 3 if executor == "list" else 2          # list: eager + record, then two replays
+    losses, g_first = [], None
+    for k in range(nsteps):
+        losses.append(float(tr.step(*_batch(10 + rank + 2 * k, dev))))
+        if k == 0:
+            torch.cuda.synchronize()
+            g_first = m.flat_grads.detach().double().cpu().numpy()
     torch.cuda.synchronize()
+    ok_oracle = True
+    if check_oracle:
+        # exchanged HIP step vs the CPU oracle: (a) the averaged gradient this rank holds after step 1 (its own shard of every
+        # bucket when sharded, everything otherwise) within 1e-3 per bucket -- Adam is scale-invariant, so a wrong 1/world only
+        # shows here; (b) the parameter update after all steps where the gradient is not noise, within 2 % of the learning rate
+        import numpy as np
+        flat1, p_ref, big = _oracle_mean_step(start_sd, m._ps, world, nsteps, 1e-3)
+        for i, (a, b) in enumerate(m.grad_buckets()):
+            b = min(b, m.caption_param_end)
+            if b <= a:
+                continue
+            lo, hi = a, b
+            if sharded and ex.shard_of(i) is not None:
+                lo, hi, _n = ex.shard_of(i)
+                hi = min(hi, b)
+            if hi <= lo:
+                continue
+            err = np.linalg.norm(g_first[lo:hi] - flat1[lo:hi]) / max(np.linalg.norm(flat1[lo:hi]), 1e-30)
+            ok_oracle &= bool(err < 1e-3)
+        sd = m.state_dict()
+        for n, ref in p_ref.items():
+            if n not in big or n.endswith("pe") or n.endswith("pos_embedding"):
+                continue
+            upd = sd[n].detach().cpu().numpy().astype(np.float64) - start_sd[n].cpu().numpy()
+            upd_ref = ref.astype(np.float64) - start_sd[n].cpu().numpy()
+            ok_oracle &= bool(np.abs(upd - upd_ref)[big[n]].max(initial=0.0) < 2e-5)
     gathered = [torch.empty_like(m.flat_params) for _ in range(world)]
     dist.all_gather(gathered, m.flat_params)
     same = all(torch.equal(gathered[0], g) for g in gathered)
@@ -71,7 +133,7 @@ def _worker(rank, world, port, dtype_name, q, sharded=False):
         r.train()
         r.flat_params.copy_(start)
         ropt = FusedAdam(r, lr=1e-3)
-        for k in range(2):
+        for k in range(nsteps):
             acc = torch.zeros_like(r.flat_grads)
             for rr in range(world):
                 r._ps.refresh_shadow(force=True)
@@ -82,20 +144,24 @@ def _worker(rank, world, port, dtype_name, q, sharded=False):
         named = lambda mm: {k: v for k, v in mm.state_dict().items()}
         a, b = named(m), named(r)
         ok_ref = all(torch.equal(a[k], b[k]) for k in a)
-    q.put((rank, same, ok_ref, losses))
+    q.put((rank, same, ok_ref and ok_oracle, losses))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded", [False, True])
+@pytest.mark.parametrize("sharded,executor", [(False, "eager"), (True, "eager"), (True, "list")])
 @pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
-def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name, sharded):
+def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name, sharded, executor):
+    """executor 'list': the exchanged step recorded ONCE (collectives included, as host commands of the list for gloo) and
+    replayed -- the executor bench.py uses at N > 1.  float32 also checks the exchanged step against the CPU oracle: the mean
+    of the two ranks' oracle gradients and the oracle's Adam."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q, sharded)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q, sharded, executor, dtype_name == "float32"))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
@@ -104,7 +170,7 @@ def test_two_ranks_one_gpu_step_equals_mean_gradient_step(dtype_name, sharded):
         assert p.exitcode == 0
     for rank, same, ok_ref, losses in res:
         assert same, "ranks ended with different parameters"
-        assert ok_ref, "exchanged step differs from the single-process step on the mean gradient"
+        assert ok_ref, "exchanged step differs from the single-process step on the mean gradient / from the CPU oracle"
         assert all(l == l and l > 0 for l in losses)
     assert res[0][3] != res[1][3]            # the ranks did see different batches
 
@@ -135,5 +201,6 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines0[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 32 and d["config"]["grad_exchange"].startswith("sharded/")
+    assert d["config"]["executor"] == "list"                      # N > 1 runs the recorded launch list by default
     assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
     assert d["loss"] == d["loss"] and "cpu_baseline" not in d

@@ -84,8 +84,8 @@ def test_side_stream_gradients_are_final_before_adam_reads_them(monkeypatch):
     spins = {"n": 0}
 
     def slow_flush(self, main=False):
-        if not main and self._dw_pending and engine._StackBase._side is not None:
-            with torch.cuda.stream(engine._StackBase._side):
+        if not main and self._dw_pending and self.side is not None:
+            with torch.cuda.stream(self.side):
                 torch.cuda._sleep(40_000_000)
             spins["n"] += 1
         return orig(self, main)
@@ -263,3 +263,82 @@ def test_vocabulary_dx_through_the_maintained_transposed_shadow(monkeypatch):
         l1 = torch.cat(losses)
         assert float((l1 - l0).abs().max()) < 2e-2 * float(l0.abs().max())
         assert float((m.flat_params - p0).abs().max()) < 5e-3
+
+
+def test_host_commands_run_in_launch_order_on_replay():
+    """ops.host_call (vct_cmdlist_host_call): host work recorded into a launch list runs at its place of every replay, after the
+    stream work enqueued before it has finished (it reads a value a preceding kernel wrote), and its failure is the replay's
+    status.  This is how host-side collectives (gloo) ride in a recorded step; RCCL collectives are plain stream work."""
+    from vct_amd import ops
+    src = torch.arange(8, dtype=torch.float32, device=DEV)
+    dst = torch.zeros(8, dtype=torch.bfloat16, device=DEV)
+    seen = []
+    ll = ops.LaunchList()
+    with ll.record():
+        ops.cast(src, dst)
+        ops.host_call(lambda: seen.append(dst.float().sum().item()))
+    assert seen == [] and len(ll) == 2
+    ll.replay()
+    src.mul_(2)
+    ll.replay()
+    torch.cuda.synchronize()
+    assert seen == [28.0, 56.0]
+    boom = ops.LaunchList()
+    with boom.record():
+        ops.host_call(lambda: 1 / 0)
+    with pytest.raises(RuntimeError):
+        boom.replay()
+
+
+def test_two_models_in_one_process_keep_their_own_recordings():
+    """A training model and an evaluation copy in one process (train.py:244-249 validates between epochs): each has its own side
+    stream and buffer generation (engine.StepContext) -- the copy's buffer growth must not drop the trainer's recordings, and
+    interleaving the two must not change either one's results."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    ref, lref, _ = _run("list", steps=6)
+
+    a = _model()
+    a._seed.fill_(1234)
+    opt = FusedAdam(a, lr=1e-3)
+    tr = CaptionTrainer(a, opt, launch_list=True)
+    b = _model(seed=11)                       # the "evaluation copy": different weights, its own parameter set
+    b.eval()
+    assert a._ps.ctx is not b._ps.ctx
+    losses, lists_seen = [], []
+    for k in range(6):
+        losses.append(tr.step(*_batch(100 + k)).clone())
+        lists_seen.append(id(next(iter(tr._lists.values()))[0]))
+        # grow the copy's buffers (a bigger batch each time) and run a recorded evaluation step + a captured decode in between
+        fb, mb_, ib = _batch(500 + k, B=6 + 2 * k, T=7 + k, S=9 + k)
+        with torch.no_grad():
+            lb = b._forward_loss(fb, mb_, ib, False)[0]
+        b.greedy_decode_ids([fb], None, max_len=6)
+        assert bool(torch.isfinite(lb).all())
+    torch.cuda.synchronize()
+    assert a._ps.ctx.side is not None and a._ps.ctx.side != b._ps.ctx.side
+    assert len(set(lists_seen)) == 1, "the copy's buffer growth dropped the trainer's recording"
+    assert torch.equal(torch.cat(losses), lref) and torch.equal(a.flat_params, ref)
+
+
+@pytest.mark.parametrize("executor", ["list", "graph"])
+def test_replay_follows_weights_loaded_outside_the_optimizer(executor):
+    """load_state_dict between two replayed steps (restoring the best checkpoint, train.py:214-216): the replayed step must
+    compute with the NEW weights -- the bf16 shadow the GEMMs read is re-cast before the replay."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+
+    def run(ex):
+        m = _model()
+        m._seed.fill_(99)
+        other = {k: v.detach().clone() for k, v in _model(seed=21).state_dict().items()}
+        opt = FusedAdam(m, lr=1e-3)
+        tr = CaptionTrainer(m, opt, use_graph=ex == "graph", launch_list=ex == "list")
+        out = []
+        for k in range(5):
+            if k == 3:
+                m.load_state_dict(other)
+            out.append(tr.step(*_batch(100 + k)).clone())
+        torch.cuda.synchronize()
+        return torch.cat(out), m.flat_params.clone()
+    l0, p0 = run("eager")
+    l1, p1 = run(executor)
+    assert torch.equal(l0, l1) and torch.equal(p0, p1)

@@ -98,6 +98,8 @@ _SIGS = {
     "vct_cmdlist_replay": (C.c_int, [vp, vp]),
     "vct_cmdlist_size": (C.c_int, [vp]),
     "vct_cmdlist_streams": (C.c_int, [vp]),
+    "vct_cmdlist_inject_status": (C.c_int, [C.c_int, vp]),
+    "vct_cmdlist_host_call": (C.c_int, [vp, vp, vp]),
     "vct_stream_wait": (C.c_int, [vp, vp]),
     "vct_sync_record": (C.c_int, [C.c_int, vp]),
     "vct_sync_wait": (C.c_int, [C.c_int, vp]),
@@ -120,6 +122,7 @@ _SIGS = {
     "vct_tap_collect": (C.c_int, [C.c_int, C.POINTER(f32), C.c_int]),
 }
 _OPTIONAL = {}
+HOST_FN = C.CFUNCTYPE(C.c_int, vp)        # int fn(void* arg): vct_cmdlist_host_call
 
 _lib = None
 

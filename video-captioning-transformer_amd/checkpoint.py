@@ -36,18 +36,24 @@ def _atomic_save(obj, path: str):
 
 
 def save_training_state(path: str, model, optimizer=None, scheduler=None, epoch: int = 0, early_stopping=None,
-                        extra: Optional[dict] = None):
+                        extra: Optional[dict] = None, write: bool = True):
+    """Data-parallel runs: EVERY rank calls this (a sharded optimizer all-gathers its Adam moments inside
+    optimizer.state_dict(): each rank only keeps the moments of the shards it owns current), and passes
+    write=(rank == 0) so that one rank writes the file."""
     seed = getattr(model, "_seed", None)
+    opt_state = _to_cpu(optimizer.state_dict()) if optimizer is not None else None      # collective when sharded
+    if not write:
+        return
     state = {
         "format": FORMAT,
         "model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-        "optimizer": _to_cpu(optimizer.state_dict()) if optimizer is not None else None,
-        "scheduler": scheduler.state_dict() if scheduler is not None else None,
+        "optimizer": _plain(opt_state),
+        "scheduler": _plain(scheduler.state_dict()) if scheduler is not None else None,
         "epoch": int(epoch),
-        "early_stopping": early_stopping.state_dict() if early_stopping is not None else None,
+        "early_stopping": _plain(early_stopping.state_dict()) if early_stopping is not None else None,
         "dropout_seed": None if seed is None else int(seed.item()),
         "torch_rng": torch.get_rng_state(),
-        "extra": extra or {},
+        "extra": _plain(extra or {}),
     }
     _atomic_save(state, path)
 
@@ -85,6 +91,21 @@ def _to_cpu(obj):
     return obj
 
 
+def _plain(obj):
+    """numpy scalars and 0-d tensors -> Python numbers (recursively): load_training_state reads with weights_only=True, which
+    refuses numpy's pickled scalar types -- e.g. a ReduceLROnPlateau.best or an early-stopping score that came from np.mean of
+    the validation losses would save fine and then fail to load."""
+    if isinstance(obj, np.generic):
+        return obj.item()
+    if torch.is_tensor(obj) and obj.dim() == 0 and obj.numel() == 1 and not obj.is_complex():
+        return obj.item()
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    return obj
+
+
 class EarlyStopping:
     """reference utils.py:8-59.  `__call__(val_loss, model, do_save)`: lower is better; the model is saved (weights
     only, like the reference) whenever the monitored value improves and do_save is True."""
@@ -119,8 +140,8 @@ class EarlyStopping:
         self.val_loss_min = val_loss
 
     def state_dict(self):
-        return {"counter": self.counter, "best_score": self.best_score, "early_stop": self.early_stop,
-                "val_loss_min": float(self.val_loss_min)}
+        return {"counter": int(self.counter), "best_score": None if self.best_score is None else float(self.best_score),
+                "early_stop": bool(self.early_stop), "val_loss_min": float(self.val_loss_min)}
 
     def load_state_dict(self, sd):
         self.counter, self.best_score, self.early_stop = sd["counter"], sd["best_score"], sd["early_stop"]

@@ -19,7 +19,12 @@ from . import _lib as L
 
 
 class C10dColl:
+    """Host-side collectives.  Inside a recorded launch list (ops.LaunchList) each call becomes a host command of the list
+    (ops.host_call): at that point of every replay the stream it was issued on is drained, the collective runs on the host
+    thread, and the device is idle again before the next recorded launch -- slow, but it lets the recorded executor carry the
+    exchange in the one-GPU multi-rank tests exactly as it carries RCCL's stream-side collectives on a real node."""
     owns_stream = False
+    recordable = True
 
     def __init__(self, group=None):
         self.group = group
@@ -27,10 +32,22 @@ class C10dColl:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stream = None
 
+    def _run(self, fn, t):
+        from . import ops
+        if t.is_cuda and ops.is_recording():
+            def at_replay():
+                fn()
+                torch.cuda.synchronize(t.device)
+            ops.host_call(at_replay)
+        else:
+            fn()
+
     def allreduce_avg(self, t, after=None):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            t.mul_(1.0 / self.world)
+            def go():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                t.mul_(1.0 / self.world)
+            self._run(go, t)
 
     def reduce_scatter_avg(self, t, n, after=None):
         """Own shard t[rank*n:(rank+1)*n) holds the mean afterwards (the other shards are unspecified)."""
@@ -38,12 +55,14 @@ class C10dColl:
 
     def all_gather(self, t, n, after=None):
         if self.world > 1:
-            mine = t[self.rank * n:(self.rank + 1) * n].clone()
-            dist.all_gather([t[q * n:(q + 1) * n] for q in range(self.world)], mine, group=self.group)
+            def go():
+                mine = t[self.rank * n:(self.rank + 1) * n].clone()
+                dist.all_gather([t[q * n:(q + 1) * n] for q in range(self.world)], mine, group=self.group)
+            self._run(go, t)
 
     def broadcast(self, t, root=0, after=None):
         if self.world > 1:
-            dist.broadcast(t, src=root, group=self.group)
+            self._run(lambda: dist.broadcast(t, src=root, group=self.group), t)
 
     def wait(self, stream=None):
         pass
@@ -54,6 +73,7 @@ class C10dColl:
 
 class RcclColl:
     owns_stream = True
+    recordable = True
 
     def __init__(self, group=None, device=None):
         lib = L.load()

@@ -150,7 +150,7 @@ static int comm_edge(Comm* c, void* after_stream, bool have_after) {
 
 template <typename F> static int comm_issue(Comm* c, F&& f) {
   if (g_rec != nullptr) {
-    rec_push(c->stream, [f](hipStream_t s) { (void)f(s); });
+    rec_push(c->stream, [f](hipStream_t s) { const int r = f(s); if (r != ncclSuccess) replay_note_error(VCT_E_RCCL + r); });
     return VCT_OK;
   }
   const int r = f(c->stream);

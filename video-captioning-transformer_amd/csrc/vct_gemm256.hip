@@ -27,6 +27,8 @@
 // per-CU store issue rate (~14 B/clk): with one workgroup per CU nothing overlaps it, de-phasing the workgroups or draining
 // the stores behind a counted vmcnt changes nothing.
 #include "vct_gemm_bf16_kernel.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace vct {
 
@@ -273,6 +275,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
   }
 }
 
+// Persistent grid = the compute units the STREAM may use (one workgroup per CU, a multiple of 8 so that blockIdx & 7 stays the
+// XCD): 256 on an unmasked MI355X stream, fewer on a CU-masked one (vct_stream_create_masked) -- a 256-workgroup grid there
+// would queue two or more 128 KB-LDS workgroups behind each other on every allowed CU.  Looked up once per stream.
+static int g256_grid(hipStream_t st) {
+  static std::mutex mu;
+  static std::unordered_map<void*, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find((void*)st);
+  if (it != cache.end()) return it->second;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+  }
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (st != nullptr && hipExtStreamGetCUMask(st, 8, mask) == hipSuccess) {
+    int n = 0;
+    for (int i = 0; i < 8; i++) n += __builtin_popcount(mask[i]);
+    if (n > 0 && n < cus) cus = n;
+  }
+  (void)hipGetLastError();                                   // a refused query must not surface at the next launch check
+  const int grid = cus >= 8 ? (cus & ~7) : 8;
+  cache.emplace((void*)st, grid);
+  return grid;
+}
+
 template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -280,7 +308,7 @@ template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hi
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  vct::launch(gemm256_kernel<TA, TB, TO>, dim3(256), dim3(512), (size_t)G256_LDS, st, p);
+  vct::launch(gemm256_kernel<TA, TB, TO>, dim3(g256_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

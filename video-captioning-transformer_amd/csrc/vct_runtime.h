@@ -12,6 +12,9 @@ namespace vct {
 struct CmdList;
 extern thread_local CmdList* g_rec;                                           // non-null while this thread records
 void rec_push(hipStream_t st, std::function<void(hipStream_t)>&& fn);         // append to g_rec
+// Replayed closures cannot return a status to their original caller: the first non-zero code noted during a replay is
+// kept (sticky) and becomes the return value of vct_cmdlist_replay -- a failed RCCL collective / event call is not silent.
+void replay_note_error(int code);
 
 template <typename K, typename... A>
 inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -24,7 +27,7 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
 
 inline hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t st) {
   if (g_rec != nullptr) {
-    rec_push(st, [=](hipStream_t s) { (void)hipMemsetAsync(p, value, bytes, s); });
+    rec_push(st, [=](hipStream_t s) { const hipError_t e = hipMemsetAsync(p, value, bytes, s); if (e != hipSuccess) replay_note_error((int)e); });
     return hipSuccess;
   }
   return hipMemsetAsync(p, value, bytes, st);

@@ -37,6 +37,8 @@ struct CmdList {
 };
 
 thread_local CmdList* g_rec = nullptr;
+static thread_local int g_replay_err = 0;          // first error noted by a closure of the replay in progress
+void replay_note_error(int code) { if (code != 0 && g_replay_err == 0) g_replay_err = code; }
 
 void rec_push(hipStream_t st, std::function<void(hipStream_t)>&& fn) {
   CmdList* l = g_rec;
@@ -72,7 +74,7 @@ static int do_record(int id, hipStream_t st) {
   if (g_rec != nullptr) {
     CmdList* l = g_rec;
     Cmd c; c.slot_a = l->slot_of(st); c.slot_b = -1;
-    c.fn = [e](hipStream_t a, hipStream_t) { (void)hipEventRecord(e, a); };
+    c.fn = [e](hipStream_t a, hipStream_t) { const hipError_t r = hipEventRecord(e, a); if (r != hipSuccess) replay_note_error((int)r); };
     l->cmds.push_back(std::move(c));
     return VCT_OK;
   }
@@ -85,7 +87,7 @@ static int do_wait(int id, hipStream_t st) {
   if (g_rec != nullptr) {
     CmdList* l = g_rec;
     Cmd c; c.slot_a = l->slot_of(st); c.slot_b = -1;
-    c.fn = [e](hipStream_t a, hipStream_t) { (void)hipStreamWaitEvent(a, e, 0); };
+    c.fn = [e](hipStream_t a, hipStream_t) { const hipError_t r = hipStreamWaitEvent(a, e, 0); if (r != hipSuccess) replay_note_error((int)r); };
     l->cmds.push_back(std::move(c));
     return VCT_OK;
   }
@@ -165,9 +167,31 @@ extern "C" int vct_cmdlist_replay(void* list, void* main_stream) {
   for (int i = 0; i < ns; i++) map[i] = l->streams[i];
   map[0] = (hipStream_t)main_stream;
   if (l->cmds.empty()) return VCT_OK;
+  g_replay_err = 0;
   for (const Cmd& c : l->cmds) c.fn(map[c.slot_a], c.slot_b >= 0 ? map[c.slot_b] : nullptr);
   const hipError_t e = hipGetLastError();
+  if (g_replay_err != 0) return g_replay_err;      // first failed collective / event call of this replay (sticky)
   return e == hipSuccess ? VCT_OK : (int)e;
+}
+
+extern "C" int vct_cmdlist_inject_status(int status, void* stream) {
+  if (g_rec == nullptr) return status;
+  rec_push((hipStream_t)stream, [status](hipStream_t) { replay_note_error(status); });
+  return VCT_OK;
+}
+
+extern "C" int vct_cmdlist_host_call(int (*fn)(void*), void* arg, void* stream) {
+  if (fn == nullptr) return VCT_E_ARG;
+  auto run = [fn, arg](hipStream_t s) -> int {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    return fn(arg);
+  };
+  if (g_rec != nullptr) {
+    rec_push((hipStream_t)stream, [run](hipStream_t s) { replay_note_error(run(s)); });
+    return VCT_OK;
+  }
+  return run((hipStream_t)stream);
 }
 
 extern "C" int vct_sync_record(int id, void* stream) {

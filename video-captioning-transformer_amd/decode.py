@@ -13,7 +13,7 @@ Two implementations with identical results (tests/test_model_gpu.py):
 import torch
 
 from . import ops
-from .engine import DecodeState, _Buf
+from .engine import DecodeState
 from .utils import capture_graph
 
 
@@ -77,7 +77,7 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
         # copies.  It bakes pointers into the engines' shared grow-only buffers: re-captured whenever any of them grew.
         key = (tuple(feats.shape), feats.dtype, mask is not None)
         bg = st.__dict__.get("begin")
-        if bg is None or bg["key"] != key or bg["gen"] != _Buf.generation:
+        if bg is None or bg["key"] != key or bg["gen"] != model._ps.ctx.generation:
             fin = torch.empty_like(feats, memory_format=torch.contiguous_format)
             min_ = torch.empty_like(mask, memory_format=torch.contiguous_format) if mask is not None else None
             fin.copy_(feats)
@@ -87,7 +87,7 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
             g = torch.cuda.CUDAGraph()
             with capture_graph(g):
                 dec.decode_begin(st, enc.forward(fin, min_, False), pre.start_id, pre.pad_id)
-            st.begin = {"key": key, "gen": _Buf.generation, "g": g, "fin": fin, "min": min_}
+            st.begin = {"key": key, "gen": model._ps.ctx.generation, "g": g, "fin": fin, "min": min_}
         else:
             bg["fin"].copy_(feats)
             if mask is not None:
@@ -137,3 +137,28 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
         if on_gpu:
             stop = min(stop, ended_as_of(max_len - 1))
     return st.ys[:, :min(stop, max_len - 1) + 1].clone()
+
+
+@torch.no_grad()
+def teacher_forced_next_ids(model, feats: torch.Tensor, mask, prefix_ids: torch.Tensor, steps: int, return_logits: bool = False):
+    """The KV-cache token step of greedy_decode_ids (same kernels, same cache) with the CONSUMED token of every step forced to
+    `prefix_ids[:, t - 1]` instead of the step's own previous prediction: returns the predicted next ids [B, steps]
+    (column t - 1 = arg-max after consuming prefix_ids[:, :t]).  This is CapDecoder.decode_word + torch.max of the reference
+    (CapDecoder.py:62-79, MMT4Caption.py:164-165) evaluated along a given caption -- what a low-precision path can be held
+    to where free-running ids would diverge after the first unresolvable logit gap.  return_logits: also the fp32 logits
+    [B, steps, V] of every step."""
+    pre = model.cap_preprocessor
+    model._ps.refresh_shadow()
+    enc, dec = model.video_encoder._engine(), model.cap_decoder._engine()
+    B, T = feats.shape[0], feats.shape[1]
+    st = DecodeState(dec, B, T + 1, steps + 1)
+    dec.decode_begin(st, enc.forward(feats, mask, False), pre.start_id, pre.pad_id)
+    out = torch.empty(B, steps, dtype=torch.long, device=feats.device)
+    logits = torch.empty(B, steps, dec.V, dtype=torch.float32, device=feats.device) if return_logits else None
+    for t in range(1, steps + 1):
+        st.ys[:, t - 1] = prefix_ids[:, t - 1]
+        dec.decode_step(st, t, pre.end_id)
+        out[:, t - 1] = st.ys[:, t]
+        if return_logits:
+            logits[:, t - 1] = st.last_logits[:, :dec.V].float()
+    return (out, logits) if return_logits else out

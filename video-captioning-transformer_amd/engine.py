@@ -26,6 +26,18 @@ ENC_SITE, DEC_SITE, EMB_SITE = 0, 1000, 999
 DMEM_SYNC = 0      # named sync point (ops.sync_record / sync_wait): d(memory) is final on the main stream
 
 
+class StepContext:
+    """Per-model execution state shared by the engines of ONE parameter set: the side HIP stream (+ its split-K scratch) that
+    weight-gradient GEMMs / the encoder backward / the decoder prefix run on, and the buffer generation counter that
+    invalidates baked pointer sets (launch lists, hipGraphs, pointer tables).  It used to be process-global: two models in one
+    process (a training model and an evaluation copy) then shared a side stream and dropped each other's recordings."""
+
+    def __init__(self):
+        self.side = None
+        self.side_ws = None
+        self.generation = 0
+
+
 class ParamSet:
     """fp32 master parameters (views of one flat buffer), their fp32 gradient views and the
     compute-dtype shadow used by the GEMMs.  Order = gradient-ready order of the backward pass so
@@ -37,6 +49,7 @@ class ParamSet:
         self.names = [n for n, _ in named]
         self.params = {n: p for n, p in named}
         self.device, self.compute_dtype = device, compute_dtype
+        self.ctx = StepContext()
         self.offsets, off = {}, 0
         for n, p in named:
             self.offsets[n] = off
@@ -133,13 +146,11 @@ class _Buf:
     """Named device buffers with STATIC addresses.  One instance serves every shape configuration of an engine:
     `get` hands out a leading view of a per-name allocation that only ever grows, so a ragged epoch (the loader trims S
     to each batch's longest caption) neither re-allocates per step nor frees memory that a captured hipGraph / recorded
-    launch list still points to.  `generation` counts (re)allocations: whoever bakes pointers (trainer graphs, launch
-    lists, pointer tables) keys its cache on it and re-records after a growth."""
+    launch list still points to.  `ctx.generation` (StepContext of the owning parameter set) counts (re)allocations: whoever
+    bakes pointers (trainer graphs, launch lists, pointer tables) keys its cache on it and re-records after a growth."""
 
-    generation = 0          # class-wide: any growth anywhere invalidates every baked pointer set
-
-    def __init__(self, device):
-        self.device, self.t, self._store = device, {}, {}
+    def __init__(self, device, ctx: "StepContext"):
+        self.device, self.t, self._store, self.ctx = device, {}, {}, ctx
 
     def get(self, name, shape, dtype):
         n = 1
@@ -149,7 +160,7 @@ class _Buf:
         if st is None or st.dtype != dtype or st.numel() < n:
             st = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._store[name] = st
-            _Buf.generation += 1
+            self.ctx.generation += 1
             for k in [k for k in self.t if isinstance(k, tuple) and k and k[0] == "ln_table"]:
                 del self.t[k]          # pointer tables baked the old addresses
         t = st[:n].view(shape)
@@ -193,27 +204,30 @@ class _StackBase:
     group_dw = True
     overlap_kv = True      # cross-attention K/V projections and d(memory) accumulation off the critical path
     defer_gen_dw = True    # single GPU: vocabulary weight gradient at the end of the main stream's tail (A/B switch)
-    _side = None
-    _side_ws = None
+
+    @property
+    def side(self):
+        """The model's side stream (None until something needed it)."""
+        return self.ps.ctx.side
 
     def ensure_side(self):
-        cls = _StackBase
-        if cls._side is None:
-            cls._side = torch.cuda.Stream(device=self.dev)
-            cls._side_ws = ops.GemmScratch(self.dev)
-        return cls._side
+        ctx = self.ps.ctx
+        if ctx.side is None:
+            ctx.side = torch.cuda.Stream(device=self.dev)
+            ctx.side_ws = ops.GemmScratch(self.dev)
+        return ctx.side
 
     def _on_side(self, fn):
         if not (self.overlap_dw and self.dev.type == "cuda"):
             return fn(self.gemm_ws())
-        cls = _StackBase
+        ctx = self.ps.ctx
         self.ensure_side()
         cur = torch.cuda.current_stream()
-        if cur == cls._side:              # already running on the side stream (encoder backward beside the decoder's tail)
-            return fn(cls._side_ws)
-        ops.stream_wait(cls._side, cur)
-        with torch.cuda.stream(cls._side):
-            return fn(cls._side_ws)
+        if cur == ctx.side:               # already running on the side stream (encoder backward beside the decoder's tail)
+            return fn(ctx.side_ws)
+        ops.stream_wait(ctx.side, cur)
+        with torch.cuda.stream(ctx.side):
+            return fn(ctx.side_ws)
 
     def dw_gemm(self, dy, x, dw, *, bias_grad=None, m_valid=None, tag=None):
         """dw[M,N] (fp32 gradient view) = dy^T x, bias_grad[M] = column sums of dy."""
@@ -240,7 +254,7 @@ class _StackBase:
         stream -- an all-reduce issued from the hook waits for this bucket's weight gradients (side stream) and
         LayerNorm/bias gradients (main stream) while the main stream goes straight on to the next layer."""
         self.flush_dw()
-        side = _StackBase._side
+        side = self.ps.ctx.side
         if side is None or not self.overlap_dw or torch.cuda.current_stream() == side:
             return bucket_ready(*args)
         ops.stream_wait(side, None)
@@ -251,15 +265,16 @@ class _StackBase:
         """Main stream waits for every weight-gradient GEMM issued so far (before a gradient bucket is
         handed to the exchange / the optimizer)."""
         self.flush_dw()
-        if _StackBase._side is not None and self.overlap_dw and torch.cuda.current_stream() != _StackBase._side:
-            ops.stream_wait(None, _StackBase._side)
+        side = self.ps.ctx.side
+        if side is not None and self.overlap_dw and torch.cuda.current_stream() != side:
+            ops.stream_wait(None, side)
 
     def buf(self, key) -> _Buf:
         """The engine's buffer set (`key` = the shape configuration, kept for diagnostics only: every configuration
         shares one set of grow-only allocations, see _Buf)."""
         b = self.bufs.get("all")
         if b is None:
-            b = self.bufs["all"] = _Buf(self.dev)
+            b = self.bufs["all"] = _Buf(self.dev, self.ps.ctx)
         return b
 
     # ---- shared sub-blocks -------------------------------------------------------------------
@@ -712,7 +727,7 @@ class DecodeState:
         self.all_ended_at = torch.full((1,), Lmax, dtype=torch.long, device=dev)   # first t at which every row had ended
         self.kv_self = [torch.zeros(Bn * Lmax, 3 * d, dtype=dt, device=dev) for _ in range(L)]    # [q | k | v] per slot
         self.kv_cross = [torch.empty(Bn * Te, 2 * d, dtype=dt, device=dev) for _ in range(L)]
-        self.b = _Buf(dev)
+        self.b = _Buf(dev, eng.ps.ctx)
         self.graphs = {}
 
 
@@ -769,6 +784,7 @@ def _decoder_decode_step(self, st: DecodeState, t: int, end_id: int):
     logits = b.get("logits", (Bn, self.Vp), self.dt)
     ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=ws)
     # arg-max into column t + sticky end flags + the first step at which every row has ended: one launch, no host sync
+    st.last_logits = logits          # [B, Vp] of this step (decode.teacher_forced_next_ids reads it)
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
@@ -779,8 +795,14 @@ def _decoder_small_decode_ok(self, st: DecodeState) -> bool:
     workgroup recomputes the attention of all (batch, head) pairs and reduces 8 x B dot products per trip), so every larger
     batch stays on the batched kernels."""
     ki = 512 if self.dt == torch.bfloat16 else 256
-    d, ff = self.cfg["d"], self.cfg["ff"]
-    return (self.small_batch_decode and st.B <= 1 and d % ki == 0 and ff % ki == 0 and d <= 2048 and ff <= 2048
+    d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
+    # the C side's limits (csrc/vct_decode.hip, vct_decode_gemv): K / ki chunks per lane in {1, 2, 4} (8: fp32 only), the
+    # LayerNorm prologues hold a whole row of K = d <= 1024 in registers, head_dim a whole number of 16-byte vectors.  Any
+    # other width (the shipped d = 768 in fp32: 3 chunks) takes the batched step instead of raising VCT_E_SHAPE.
+    def chunks_ok(k):
+        return k % ki == 0 and (k // ki in (1, 2, 4) or (k // ki == 8 and self.dt == torch.float32))
+    vec = 8 if self.dt == torch.bfloat16 else 4
+    return (self.small_batch_decode and st.B <= 1 and chunks_ok(d) and chunks_ok(ff) and d <= 1024 and (d // H) % vec == 0
             and st.Lmax <= 64 and st.Te <= 64 and self.dev.type == "cuda")
 
 
@@ -824,6 +846,7 @@ def _decoder_decode_step_small(self, st: DecodeState, t: int, end_id: int):
     logits = b.get("slogits", (B, self.Vp), f32)
     ops.decode_gemv(self.W("generator.weight"), logits, B, bias=self.F("generator.bias"), pro="ln_ln", x_in=s3, ln1=prev_norm,
                     ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), n_valid=self.V)
+    st.last_logits = logits          # [B, Vp] of this step (decode.teacher_forced_next_ids reads it)
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
@@ -879,6 +902,7 @@ def _decoder_decode_step_fused(self, st: DecodeState, t: int, end_id: int):
     ops.decode_ln2(xin, prev_norm, (self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), y)
     logits = b.get("logits", (Bn, self.Vp), self.dt)
     ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=self.gemm_ws())
+    st.last_logits = logits          # [B, Vp] of this step (decode.teacher_forced_next_ids reads it)
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 

@@ -186,8 +186,6 @@ class MMT4Caption(nn.Module):
         if self.overlap_enc_bwd and dec.dev.type == "cuda" and dec.overlap_dw:
             # the encoder's backward only needs d(memory): it runs on the side stream beside the decoder's bottom
             # self-attention backward and the embedding gradient (two chains of small kernels share the chip)
-            from ..engine import _StackBase
-
             def launch(dmem, dmem_point):
                 side = dec.ensure_side()
                 ops.sync_wait(dmem_point, side)                   # d(memory) final (its last accumulate is on `side` itself)

@@ -414,6 +414,33 @@ def sync_wait(ident: int, stream=None):
     L.check(L.load().vct_sync_wait(int(ident), _sptr(stream)), "vct_sync_wait")
 
 
+_recording = False      # a LaunchList is recording on this thread (host-side collectives then go through host_call)
+
+
+def is_recording() -> bool:
+    return _recording
+
+
+_host_fns = []          # CFUNCTYPE objects handed to vct_cmdlist_host_call: recorded lists call them for as long as they live
+
+
+def host_call(fn, stream=None):
+    """Run the Python callable `fn()` on the host once everything enqueued on `stream` (None = current) so far has finished --
+    immediately, or at this point of every replay while a launch list records (include/vct_hip.h, vct_cmdlist_host_call).  For
+    host-side collectives (torch.distributed / gloo) inside a recorded step; an exception in fn becomes status 1 of the replay."""
+    def thunk(_arg):
+        try:
+            fn()
+            return 0
+        except Exception:                     # never unwind through the C frames of the replay loop
+            import traceback
+            traceback.print_exc()
+            return 1
+    cfn = L.HOST_FN(thunk)
+    _host_fns.append(cfn)
+    L.check(L.load().vct_cmdlist_host_call(L.C.cast(cfn, L.vp), None, _sptr(stream)), "vct_cmdlist_host_call")
+
+
 def masked_stream(cu_bits, device=None):
     """torch stream restricted to the compute units whose indices are in `cu_bits` (iterable of ints < 256); an empty /
     None selection gives an ordinary stream.  Wraps vct_stream_create_masked; the stream lives as long as the process."""
@@ -473,10 +500,14 @@ class LaunchList:
             self.ll = ll
 
         def __enter__(self):
+            global _recording
             L.check(L.load().vct_cmdlist_begin(self.ll._h, L.stream_ptr()), "vct_cmdlist_begin")
+            _recording = True
             return self.ll
 
         def __exit__(self, *exc):
+            global _recording
+            _recording = False
             L.check(L.load().vct_cmdlist_end(self.ll._h), "vct_cmdlist_end")
             return False
 

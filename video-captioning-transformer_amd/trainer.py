@@ -105,6 +105,10 @@ class ShardedExchange:
             coll.broadcast(model.flat_params, 0)
             coll.wait()
             model._ps.refresh_shadow(force=True)
+        # each rank steps exp_avg / exp_avg_sq on its own shards only: the optimizer's state_dict() (checkpoints) must see
+        # the gathered moments, so it calls back here first -- on every rank, it is a collective
+        if self.sharded and self.world > 1 and hasattr(opt, "pre_state_dict"):
+            opt.pre_state_dict = self.gather_optimizer_state
 
     def _on_comm(self):
         return torch.cuda.stream(self.coll.stream) if self.coll.owns_stream else _NullCtx()
@@ -194,6 +198,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.hyper = torch.zeros(8, dtype=torch.float32, device=ps.flat.device)
         self._hyper_host = None
         self.sync_hyper()
+        self.pre_state_dict = None      # set by ShardedExchange: all-gather the moments before they are read (collective)
 
     def _hyper_now(self):
         g = self.param_groups[0]
@@ -241,6 +246,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- checkpointing (checkpoint.save_training_state): moments and step live outside torch's per-param state ----
     def state_dict(self):
+        if self.pre_state_dict is not None:
+            self.pre_state_dict()
         sd = super().state_dict()
         ps = self.model._ps
         sd["vct_fused_adam"] = {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
@@ -304,16 +311,17 @@ class CaptionTrainer:
         two-stream semantics without the Python/ctypes cost per launch;
       * use_graph=True: the step is captured into a hipGraph (bitwise equal, but replay serialises the two streams).
     Inputs are copied into static buffers; the dropout seed, the Adam step counter and the Adam hyper-parameters live
-    in device memory, so every replay sees fresh values.  Recordings are dropped when an activation buffer had to grow
-    (engine._Buf.generation), because they bake device pointers."""
+    in device memory, so every replay sees fresh values.  Recordings are dropped when an activation buffer of THIS model had
+    to grow (engine.StepContext.generation), because they bake device pointers."""
 
     def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None, use_graph: bool = False,
                  launch_list: Optional[bool] = None):
         self.model, self.opt, self.ex = model, optimizer, exchange
         model._unit_loss_grad = True
         single = (exchange is None or not exchange.active) and isinstance(optimizer, FusedAdam)
-        # a launch list can also carry the exchange when every collective goes through the library's communicator
-        listable = single or (isinstance(exchange, ShardedExchange) and exchange.coll.owns_stream)
+        # a launch list can also carry the exchange when every collective is recordable: stream work of the library's own RCCL
+        # communicator, or host commands of the list (comm.C10dColl under ops.host_call: the one-GPU multi-rank tests)
+        listable = single or (isinstance(exchange, ShardedExchange) and getattr(exchange.coll, "recordable", False))
         self.use_graph = bool(use_graph) and single
         self.use_list = (bool(launch_list) if launch_list is not None else False) and listable and not self.use_graph
         self._graphs = {}
@@ -352,11 +360,11 @@ class CaptionTrainer:
         elif fused and self.overlap_adam and feats.is_cuda:
             # single GPU: Adam on each gradient bucket the moment backward completes it, on the side stream, so the
             # 1.4 GB optimizer pass hides under the rest of backward instead of trailing it
-            from .engine import _StackBase
             buckets = m.grad_buckets()
+            ctx = m._ps.ctx
 
             def hook(i):
-                side = _StackBase._side
+                side = ctx.side
                 if side is None:
                     self.opt.step_range(*buckets[i])
                     return
@@ -364,8 +372,8 @@ class CaptionTrainer:
                 with torch.cuda.stream(side):
                     self.opt.step_range(*buckets[i])
             loss = m.train_step_kernels(feats, mask, ids, bucket_ready=hook)   # zero_grad is implicit: grads are overwritten
-            if _StackBase._side is not None:
-                ops.stream_wait(None, _StackBase._side)
+            if ctx.side is not None:
+                ops.stream_wait(None, ctx.side)
             self.opt.finish_ranges()
         elif fused and feats.is_cuda and m.overlap_enc_bwd and not self.adam_after_backward:
             # the encoder backward is still running on the side stream when the decoder's tail is done: Adam on everything
@@ -390,6 +398,12 @@ class CaptionTrainer:
             ops.advance_seed(m._seed)
         ops.tap("step", 1)
         return loss
+
+    def _fresh_shadow(self):
+        """Replays skip _step_kernels, which is where the bf16 shadow / transposed copies follow the fp32 masters: if the
+        masters were written outside FusedAdam since the last step (load_state_dict, load_weights, restoring the best
+        checkpoint), re-cast them eagerly on the current stream before the replay (host-only version-stamp check otherwise)."""
+        self.model._ps.refresh_shadow()
 
     def drop_recordings(self):
         """Forget every recorded launch list / captured graph (they are re-made on the next step of each shape): needed after
@@ -433,11 +447,11 @@ class CaptionTrainer:
             self.opt.sync_hyper()
         if not (self.use_graph or self.use_list):
             return self._step_kernels(feats, mask, ids)
-        from .engine import _Buf
-        if self._gen != _Buf.generation:          # a buffer grew since the recordings were made: they bake stale pointers
+        ctx = self.model._ps.ctx                  # this model's buffers / side stream (engine.StepContext)
+        if self._gen != ctx.generation:           # a buffer grew since the recordings were made: they bake stale pointers
             self._graphs.clear()
             self._lists.clear()
-            self._gen = _Buf.generation
+            self._gen = ctx.generation
         key = self._input_key(feats, mask, ids)
         static = self._static_inputs(key, feats, mask, ids)
         if self.use_list:
@@ -446,24 +460,25 @@ class CaptionTrainer:
                 # first step of this shape: run it eagerly on the static copies (allocates every buffer), then record the
                 # same schedule (recording executes nothing); later calls replay the recording
                 eager_loss = self._step_kernels(*static).clone()
-                if self._gen != _Buf.generation:      # the eager step allocated: older recordings are stale, this one is not made yet
+                if self._gen != ctx.generation:       # the eager step allocated: older recordings are stale, this one is not made yet
                     self._graphs.clear()
                     self._lists.clear()
-                    self._gen = _Buf.generation
+                    self._gen = ctx.generation
                 ll = ops.LaunchList()
                 with ll.record():
                     loss = self._step_kernels(*static)
                 self._lists[key] = (ll, loss)
                 return eager_loss
+            self._fresh_shadow()
             ll[0].replay()
             return ll[1]
         g = self._graphs.get(key)
         if g is None:
             eager_loss = self._step_kernels(*static).clone()
-            if self._gen != _Buf.generation:
+            if self._gen != ctx.generation:
                 self._graphs.clear()
                 self._lists.clear()
-                self._gen = _Buf.generation
+                self._gen = ctx.generation
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
@@ -475,6 +490,7 @@ class CaptionTrainer:
             self._graphs[key] = (graph, loss)
             return eager_loss
         graph, loss = g
+        self._fresh_shadow()
         graph.replay()
         return loss
 

@@ -44,7 +44,14 @@ def configure_hardware(backend: str = None):
     use_cuda = torch.cuda.is_available() and backend != "gloo"
     backend = os.environ.get("VCT_DIST_BACKEND", backend)     # tests: several ranks on ONE GPU talk over gloo
     if use_cuda:
-        local = local % max(torch.cuda.device_count(), 1)
+        n_dev = max(torch.cuda.device_count(), 1)
+        if local >= n_dev:
+            # more local ranks than visible GPUs: only the one-GPU multi-rank TESTS want that (they set VCT_DIST_BACKEND=gloo);
+            # a real launch that over-subscribes a GPU would silently halve every rank's throughput -- refuse it
+            if os.environ.get("VCT_DIST_BACKEND") is None:
+                raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible: one process per GPU "
+                                   "(set VCT_DIST_BACKEND=gloo to share a GPU between ranks in tests)")
+            local = local % n_dev
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
