@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 4
+#define VCT_ABI_VERSION 5
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -163,6 +163,36 @@ int vct_attn_block_supported(int dtype, int H, int hd, int Lq, int Lk);
 int vct_attn_block_fwd(const vct_attn_block_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-complete nn.Linear + dropout + residual + LayerNorm (+ optional second LayerNorm) in ONE launch (bf16):
+ *     a = x W^T + bias  (x [M,K], W [d,K]);  y = LayerNorm(res + dropout(a));  y2 = LayerNorm2(y) when gamma2 != NULL.
+ * replaces: out_proj (torch nn/functional.py:6637) / linear2 + dropoutN + residual add + normN of an encoder / decoder layer
+ * (torch nn/modules/transformer.py:951-957,980-982,1143-1167,1197-1199, built at MMEncoder.py:236-238, CapDecoder.py:18-20)
+ * and, with gamma2, the stack-final LayerNorm (MMEncoder.py:238, CapDecoder.py:20) -- vct_gemm + vct_add_ln_fwd
+ * (+ vct_add_ln_fwd) on the unfused path.  Saves exactly what those save: a_out (bf16 a, may be NULL), mean / rstd
+ * (fp32 [M]), y; the dropout counter stream is vct_add_ln_fwd's (site, row * d + col), so the unfused backward kernels
+ * run unchanged behind it.  res may be NULL.  rows_per_wg: 0 = automatic, 16 or 32.
+ * vct_linear_ln_supported: 1 when (dtype, d, K) is covered (bf16, d = 512, K a multiple of 64).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_linear_ln_desc {
+  int32_t dtype, M, d, K;
+  const void* x; int64_t ldx;
+  const void* w; int64_t ldw;
+  const float* bias;
+  const void* res; int64_t ld_res;
+  const uint32_t* seed; uint32_t site; float p_drop;
+  const float* gamma; const float* beta;
+  void* a_out; int64_t ld_a;
+  void* y; int64_t ld_y;
+  float* mean; float* rstd;
+  const float* gamma2; const float* beta2;
+  void* y2; int64_t ld_y2;
+  float* mean2; float* rstd2;
+  int32_t rows_per_wg, reserved;
+} vct_linear_ln_desc;
+int vct_linear_ln_supported(int dtype, int d, int K);
+int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).
  * replaces: dropoutN + residual add + nn.LayerNorm (torch nn/modules/transformer.py:951-957,
  * 1143-1153) and the stack-final norms (MMEncoder.py:238, CapDecoder.py:20).
@@ -174,6 +204,11 @@ int vct_attn_block_fwd(const vct_attn_block_desc* d, void* stream);
 int vct_add_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma,
                    const float* beta, void* y, float* mean, float* rstd, const uint32_t* seed,
                    uint32_t site, float p_drop, void* stream);
+/* the same with the stack-final norm behind it, one launch: y2 = LayerNorm2(y) (gamma2 / beta2), built on the rows of y as
+ * stored -- the last layer's norm2 / norm3 + transformer_encoder.norm / decoder.norm (MMEncoder.py:238, CapDecoder.py:20) */
+int vct_add_ln_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma, const float* beta,
+                      void* y, float* mean, float* rstd, const float* gamma2, const float* beta2, void* y2, float* mean2,
+                      float* rstd2, const uint32_t* seed, uint32_t site, float p_drop, void* stream);
 int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,
                    const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
                    float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
@@ -200,13 +235,16 @@ int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* dz, void* d
  * ids: int64 [N] read with element stride id_stride from ids + b*id_batch_stride (so the token-shift
  * view tgt[:, :-1] needs no copy): token n = (b = n / S, s = n % S) -> ids[b*id_batch_stride + s].
  * bwd: dtable fp32 [V,d] = scatter-add of dx rows (deterministic order), row pad_id zero.
- *      id_ws: int32 [2*V] scratch (first-occurrence / count tables, built with integer atomics).
+ *      id_ws: int32 [3*V + 1] scratch: first-occurrence / count tables (built with integer atomics) and the list of
+ *      table rows this call wrote.  incremental != 0: dtable is known to be zero outside the rows the PREVIOUS call (same
+ *      dtable, same id_ws, nothing else writing dtable in between) listed there, so only those rows are zeroed (10 MB instead
+ *      of 62.5 MB at cfg-B); incremental == 0 zeroes all V rows.
  * --------------------------------------------------------------------------------------------- */
 int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids, int64_t id_batch_stride,
                   const void* table, const float* pos, void* x, const uint32_t* seed, uint32_t site,
                   float p_drop, void* stream);
 int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                  int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, const uint32_t* seed,
+                  int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int incremental, const uint32_t* seed,
                   uint32_t site, float p_drop, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ SHAPES = [  # name, ta, tb, M, N, K, out
 ]
 
 
-def run(name, ta, tb, M, N, K, odt, tile, iters=20):
+def run(name, ta, tb, M, N, K, odt, tile, iters=20, workspace=True):
     Kp, Np, Mp = (K + 31) // 32 * 32, (N + 31) // 32 * 32, (M + 31) // 32 * 32
     a = (torch.randn((Kp, Mp) if ta else (M, Kp), device=DEV)).to(torch.bfloat16)
     b = (torch.randn((N, Kp) if tb else (Kp, Np), device=DEV)).to(torch.bfloat16)
@@ -42,7 +42,8 @@ def run(name, ta, tb, M, N, K, odt, tile, iters=20):
     d = L.GemmDesc()
     d.dtype, d.out_dtype, d.ta, d.tb, d.M, d.N, d.K = L.BF16, L.dtype_code(odt), ta, tb, M, N, K
     d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if workspace:        # (the engine's layer GEMMs pass none: no split-K)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.reserved = tile
     st = L.stream_ptr()
     for _ in range(3):

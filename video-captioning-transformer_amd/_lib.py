@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -43,6 +43,14 @@ class AttnBlockDesc(C.Structure):
                 ("mean", vp), ("rstd", vp), ("site_res", u32), ("reserved", i32)]
 
 
+class LinearLnDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("M", i32), ("d", i32), ("K", i32), ("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("bias", vp),
+                ("res", vp), ("ld_res", i64), ("seed", vp), ("site", u32), ("p_drop", f32), ("gamma", vp), ("beta", vp),
+                ("a_out", vp), ("ld_a", i64), ("y", vp), ("ld_y", i64), ("mean", vp), ("rstd", vp),
+                ("gamma2", vp), ("beta2", vp), ("y2", vp), ("ld_y2", i64), ("mean2", vp), ("rstd2", vp),
+                ("rows_per_wg", i32), ("reserved", i32)]
+
+
 class DecodeGemvDesc(C.Structure):
     _fields_ = [("wdtype", i32), ("B", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i64), ("bias", vp), ("pro", i32), ("act", i32),
                 ("x_in", vp), ("ld_x", i64), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp),
@@ -72,14 +80,17 @@ _SIGS = {
     "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), vp]),
+    "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "vct_linear_ln_fwd": (C.c_int, [C.POINTER(LinearLnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_add_ln_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_ln_ws_rows": (C.c_int, [C.c_int]),
     "vct_ln_param_finalize_batched": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "vct_enc_frontend_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "vct_enc_frontend_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "vct_embed_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, u32, f32, vp]),
-    "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, C.c_int, vp, u32, f32, vp]),
     "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),

@@ -9,7 +9,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvct_hip.so")
-SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_gemm256.hip", "vct_gemm_skinny.hip", "vct_attn.hip", "vct_attn_block.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_decode.hip", "vct_runtime.hip", "vct_comm.hip"]
+SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_gemm256.hip", "vct_gemm_skinny.hip", "vct_attn.hip", "vct_attn_block.hip", "vct_linear_ln.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_decode.hip", "vct_runtime.hip", "vct_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
@@ -45,14 +45,28 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
+    # per-object stamps: a source is recompiled when it, any header, or the flags changed (editing one .hip rebuilds one object)
+    hh = hashlib.sha256(" ".join(FLAGS).encode())
+    for fn in sorted(os.listdir(CSRC)) + ["../../include/vct_hip.h"]:
+        if fn.endswith(".h"):
+            with open(os.path.join(CSRC, fn), "rb") as f:
+                hh.update(fn.encode() + f.read())
+    hdr_dig = hh.hexdigest()
+
     def cc(src):
         obj = os.path.join(PKG, "build", src.replace(".hip", ".o"))
+        with open(os.path.join(CSRC, src), "rb") as f:
+            odig = hashlib.sha256(hdr_dig.encode() + f.read()).hexdigest()
+        if not force and os.path.exists(obj) and _read(obj + ".stamp") == odig:
+            return obj
         cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
         if verbose and r.stderr.strip():
             print(r.stderr)
+        with open(obj + ".stamp", "w") as f:
+            f.write(odig)
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(srcs)) as ex:

@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int N, int S, int d, con
 // table row; a token seen once (the common case) is a straight row copy, a repeated token sums its
 // occurrences in increasing position order.  Bitwise reproducible; dtable is zero-filled first.
 __global__ void embed_index_kernel(int N, int S, const int64_t* __restrict__ ids, int64_t id_bstride, int64_t pad_id,
-                                   int32_t* __restrict__ first_pos, int32_t* __restrict__ cnt) {
+                                   int32_t* __restrict__ first_pos, int32_t* __restrict__ cnt, int32_t* __restrict__ dirty) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) dirty[0] = 0;           // the prep kernel in front has consumed the list; the scatter behind refills it
   if (n >= N) return;
   const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
   if (id == pad_id) return;
@@ -106,8 +107,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, const int64_t* __restrict__ ids,
                                                         int64_t id_bstride, int64_t pad_id, const T* __restrict__ dx,
                                                         float* __restrict__ dtable, const int32_t* __restrict__ first_pos,
-                                                        const int32_t* __restrict__ cnt, const uint32_t* seed, uint32_t site,
-                                                        float p_drop) {
+                                                        const int32_t* __restrict__ cnt, int32_t* __restrict__ dirty,
+                                                        const uint32_t* seed, uint32_t site, float p_drop) {
   constexpr int VEC = EV<T>::VEC;
   using P = PackT<T, VEC>;
   __shared__ int s_wcnt[16];
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
   const int n = blockIdx.x;
   const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
   if (id == pad_id || first_pos[id] != n) return;       // not the owner of this table row
+  if (threadIdx.x == 0) dirty[1 + atomicAdd(&dirty[0], 1)] = (int32_t)id;   // rows this call writes (next call zeroes exactly these)
   const int occurrences = cnt[id];
   const Dropout dr = make_dropout(seed, site, p_drop);
   // thread = (occurrence slot, 16-byte column chunk): a frequent token ([CLS] sits in every caption)
@@ -138,19 +140,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
   } else {
     int seen = 0;                                       // occurrences consumed so far (global order index)
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    for (int base = n; base < N && seen < occurrences; base += 1024) {
-      // ordered compaction of the matches among positions [base, base + 1024): the four id loads of a thread are
-      // issued together, one ballot per wave and 256-position slice, ONE barrier, prefix over (slice, wave)
-      bool match[4];
-      unsigned long long bal[4];
+    // ordered compaction of the matches among positions [base, base + SUBS * 256): the SUBS id loads of a thread are issued
+    // together, one ballot per wave and 256-position slice, ONE barrier, prefix over (slice, wave).  (SUBS = 20 -- the 4864
+    // positions of cfg-B in one round instead of five -- was measured and is SLOWER, 65 vs 44 us: the 20 KB position list is
+    // LDS of every one of the N workgroups, most of which copy a single row, and costs them their occupancy.)
+    constexpr int SUBS = 4;
+    for (int base = n; base < N && seen < occurrences; base += SUBS * 256) {
+      bool match[SUBS];
+      unsigned long long bal[SUBS];
 #pragma unroll
-      for (int sub = 0; sub < 4; sub++) {
+      for (int sub = 0; sub < SUBS; sub++) {
         const int j = min(base + sub * 256 + (int)threadIdx.x, N - 1);
         match[sub] = ids[(size_t)(j / S) * id_bstride + (j % S)] == id;
       }
       __syncthreads();                                  // the previous round's readers of s_list / s_wcnt are done
 #pragma unroll
-      for (int sub = 0; sub < 4; sub++) {
+      for (int sub = 0; sub < SUBS; sub++) {
         match[sub] = match[sub] && (base + sub * 256 + (int)threadIdx.x < N);
         bal[sub] = __ballot(match[sub]);
         if (l == 0) s_wcnt[sub * 4 + w] = __popcll(bal[sub]);
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
       __syncthreads();
       int total = 0;
 #pragma unroll
-      for (int sub = 0; sub < 4; sub++) {
+      for (int sub = 0; sub < SUBS; sub++) {
 #pragma unroll
         for (int ww = 0; ww < 4; ww++) {
           if (ww == w && match[sub]) s_list[total + __popcll(bal[sub] & ((1ull << l) - 1ull))] = base + sub * 256 + threadIdx.x;
@@ -500,30 +505,53 @@ extern "C" int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids,
   return VCT_OK;
 }
 
+// ONE launch in front of the scatter (it was three hipMemsetAsync calls = five fill kernels, 44 us): the occurrence tables
+// are reset and the dense gradient is zeroed -- all V rows, or (incremental) only the rows the PREVIOUS call wrote, whose ids
+// that call left in the dirty list: 4864 rows of 2 KB instead of 62.5 MB.
+namespace vct {
+__global__ __launch_bounds__(256) void embed_prep_kernel(int V, int d, float* __restrict__ dtable, int32_t* __restrict__ first_pos,
+                                                         int32_t* __restrict__ cnt, int32_t* __restrict__ dirty, int incremental) {
+  const int gt = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+  for (int i = gt; i < V; i += nth) { first_pos[i] = 0x7f7f7f7f; cnt[i] = 0; }
+  const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (!incremental) {
+    float4* dst = reinterpret_cast<float4*>(dtable);
+    const size_t n4 = (size_t)V * d / 4;
+    for (size_t i = gt; i < n4; i += nth) dst[i] = z;
+  } else {
+    const int nd = dirty[0], d4 = d / 4;
+    const int w = gt >> 6, nw = nth >> 6, lane = threadIdx.x & 63;
+    for (int r = w; r < nd; r += nw) {                     // one wave per dirty row
+      float4* dst = reinterpret_cast<float4*>(dtable + (size_t)dirty[1 + r] * d);
+      for (int c = lane; c < d4; c += 64) dst[c] = z;
+    }
+  }
+}
+}  // namespace vct
+
 extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                             int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, const uint32_t* seed,
+                             int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int incremental, const uint32_t* seed,
                              uint32_t site, float p_drop, void* stream) {
   if (!dt_ok(dtype) || !ids || !dx || !dtable || !id_ws) return VCT_E_ARG;
   if (B <= 0 || S <= 0 || d <= 0 || V <= 0) return VCT_E_SHAPE;
-  if (d % vec_of(dtype) || d / vec_of(dtype) > 256) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
+  if (d % vec_of(dtype) || d / vec_of(dtype) > 256 || (d % 4)) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
+  if (((uintptr_t)dtable & 15)) return VCT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = vct::memset_async(dtable, 0, (size_t)V * d * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
+  const int N = B * S;
   int32_t* first_pos = id_ws;
   int32_t* cnt = id_ws + V;
-  e = vct::memset_async(first_pos, 0x7f, (size_t)V * sizeof(int32_t), st);   // 0x7f7f7f7f: larger than any position
-  if (e != hipSuccess) return (int)e;
-  e = vct::memset_async(cnt, 0, (size_t)V * sizeof(int32_t), st);
-  if (e != hipSuccess) return (int)e;
-  const int N = B * S;
-  vct::launch(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt);
+  int32_t* dirty = id_ws + 2 * (size_t)V;                  // [0] = count, [1 ..] = ids of the rows written by the last call
+  vct::launch(embed_prep_kernel, dim3(incremental ? 512 : 2048), dim3(256), 0, st, V, d, dtable, first_pos, cnt, dirty,
+              incremental ? 1 : 0);
+  VCT_CHECK_LAUNCH();
+  vct::launch(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt, dirty);
   VCT_CHECK_LAUNCH();
   if (dtype == VCT_BF16)
     vct::launch((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const bf16_t*)dx, dtable, first_pos, cnt, seed, site, p_drop);
+                       (const bf16_t*)dx, dtable, first_pos, cnt, dirty, seed, site, p_drop);
   else
     vct::launch((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const float*)dx, dtable, first_pos, cnt, seed, site, p_drop);
+                       (const float*)dx, dtable, first_pos, cnt, dirty, seed, site, p_drop);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -316,12 +316,16 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   pl.nkt = (d->K + BK - 1) / BK;
   auto tiles = [&](int bm, int bn) { return (long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
   if (bf) {
-    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int cand[7][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {320, 128}, {64, 128}};
     int pick = 3;
     const int tsel = d->reserved % 10;
     pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
+    const bool cover_ok = d->out_dtype == VCT_BF16 && d->ta == 0;      // the cover tiles exist for bf16-out NT / NN
     if (tsel == 5) { pick = 0; pl.waves8 = 1; }        // 128x128, 8 waves
     else if (tsel == 8) { pick = 1; pl.waves8 = 4; }   // 128x64, 8 waves
+    else if (tsel == 6 && cover_ok) { pick = 4; pl.waves8 = 6; pl.nbuf = 2; }   // 256x128, 8 waves (4 x 2)
+    else if (tsel == 7 && cover_ok) { pick = 5; pl.waves8 = 7; pl.nbuf = 2; }   // 320x128, 8 waves (4 x 2)
+    else if (tsel == 9 && cover_ok) { pick = 6; pl.waves8 = 9; pl.nbuf = 2; }   // 64x128, 8 waves (2 x 4)
     else if (tsel >= 1 && tsel <= 4) pick = tsel - 1;
     else {
       // measured on MI355X (tools/gemm_bench.py, cfg-B shapes).  The kernel is bound by the rate at which a CU

@@ -577,6 +577,15 @@ static int launch_tiles(const GemmP& p, int bm, int bn, dim3 grid, hipStream_t s
     // 256x128 with 8 waves, single or double buffered: 320-570 TF where 128x128 gives 550-780) lose to these two everywhere
     if (p.waves8 == 1 && bm == 128 && bn == 128) VCT_LW(128, 128, 2, 4);
     else if (p.waves8 == 4 && bm == 128 && bn == 64) VCT_LW(128, 64, 4, 2);
+    else if constexpr (sizeof(TO) == 2 && TA == 0 && NBUF == 2) {
+      // "cover" tiles for the layer GEMMs (bf16 out, NT / NN): ONE workgroup per CU and about one tile per CU, so that a
+      // mid-size product (M = 3328 / 4864 rows) is a single round of workgroups at 85-128 FLOP per fetched byte instead of
+      // 1.2-2.4 rounds at 32-43 -- every tile shape of this kernel is bound by the L2 -> LDS operand rate per CU
+      if (p.waves8 == 6 && bm == 256 && bn == 128) VCT_LW(256, 128, 4, 2);
+      else if (p.waves8 == 7 && bm == 320 && bn == 128) VCT_LW(320, 128, 4, 2);
+      else if (p.waves8 == 9 && bm == 64 && bn == 128) VCT_LW(64, 128, 2, 4);
+      else return VCT_E_SHAPE;
+    }
     else return VCT_E_SHAPE;
 #undef VCT_LW
   }

@@ -16,12 +16,16 @@ template <> struct LnCfg<bf16_t> { static constexpr int VEC = 8, MAXIT = 2; };
 
 template <typename T, int VEC> struct alignas(16) RowVec { T v[VEC]; };
 
-template <typename T>
+// second LayerNorm of the same row (the stack-final norm behind the last layer's norm: MMEncoder.py:238, CapDecoder.py:20):
+// y2 = LayerNorm2(y) computed from the rows as STORED (rounded to T), i.e. what a separate launch would read back
+struct Ln2P { const float* gamma; const float* beta; void* y; float* mean; float* rstd; };
+
+template <typename T, bool TWO>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          T* __restrict__ y, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, const uint32_t* seed, uint32_t site,
-                                                         float p_drop) {
+                                                         float p_drop, const Ln2P n2) {
   constexpr int VEC = LnCfg<T>::VEC, MAXIT = LnCfg<T>::MAXIT;
   using RV = RowVec<T, VEC>;
   const int lane = threadIdx.x & 63;
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* 
   const float var = wave_sum(sq) / (float)d;
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  float sum2 = 0.0f;
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
     const int vi = it * 64 + lane;
@@ -72,8 +77,37 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* 
       for (int j = 0; j < VEC; j++) {
         const int c = vi * VEC + j;
         out.v[j] = from_f<T>((s[it][j] - mean) * rstd * gamma[c] + beta[c]);
+        if constexpr (TWO) { s[it][j] = to_f<T>(out.v[j]); sum2 += s[it][j]; }
       }
       *reinterpret_cast<RV*>(y + (size_t)row * d + vi * VEC) = out;
+    }
+  }
+  if constexpr (TWO) {
+    const float m2 = wave_sum(sum2) / (float)d;
+    float sq2 = 0.0f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { const float c = s[it][j] - m2; sq2 += c * c; }
+      }
+    }
+    const float r2 = 1.0f / sqrtf(wave_sum(sq2) / (float)d + 1e-5f);
+    if (lane == 0) { n2.mean[row] = m2; n2.rstd[row] = r2; }
+    T* y2 = reinterpret_cast<T*>(n2.y);
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec) {
+        RV out;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const int c = vi * VEC + j;
+          out.v[j] = from_f<T>((s[it][j] - m2) * r2 * n2.gamma[c] + n2.beta[c]);
+        }
+        *reinterpret_cast<RV*>(y2 + (size_t)row * d + vi * VEC) = out;
+      }
     }
   }
 }
@@ -252,22 +286,38 @@ static int ln_check(int dtype, int M, int d) {
   return VCT_OK;
 }
 
+static int add_ln_fwd_launch(int dtype, int M, int d, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                             float* mean, float* rstd, const uint32_t* seed, uint32_t site, float p_drop, const Ln2P& n2, bool two,
+                             hipStream_t st) {
+  const dim3 grid((M + 3) / 4);
+#define VCT_LN_GO(T_, TWO_)                                                                                                   \
+  vct::launch((add_ln_fwd_kernel<T_, TWO_>), grid, dim3(256), 0, st, M, d, (const T_*)x, (const T_*)res, gamma, beta, (T_*)y, mean, \
+              rstd, seed, site, p_drop, n2)
+  if (dtype == VCT_BF16) { if (two) VCT_LN_GO(bf16_t, true); else VCT_LN_GO(bf16_t, false); }
+  else { if (two) VCT_LN_GO(float, true); else VCT_LN_GO(float, false); }
+#undef VCT_LN_GO
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
 extern "C" int vct_add_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma,
                               const float* beta, void* y, float* mean, float* rstd, const uint32_t* seed,
                               uint32_t site, float p_drop, void* stream) {
   int rc = ln_check(dtype, M, d);
   if (rc) return rc;
   if (!x || !gamma || !beta || !y || !mean || !rstd) return VCT_E_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((M + 3) / 4);
-  if (dtype == VCT_BF16)
-    vct::launch((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)x, (const bf16_t*)res,
-                       gamma, beta, (bf16_t*)y, mean, rstd, seed, site, p_drop);
-  else
-    vct::launch((add_ln_fwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)x, (const float*)res,
-                       gamma, beta, (float*)y, mean, rstd, seed, site, p_drop);
-  VCT_CHECK_LAUNCH();
-  return VCT_OK;
+  const Ln2P none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  return add_ln_fwd_launch(dtype, M, d, x, res, gamma, beta, y, mean, rstd, seed, site, p_drop, none, false, (hipStream_t)stream);
+}
+
+extern "C" int vct_add_ln_ln_fwd(int dtype, int M, int d, const void* x, const void* res, const float* gamma, const float* beta,
+                                 void* y, float* mean, float* rstd, const float* gamma2, const float* beta2, void* y2, float* mean2,
+                                 float* rstd2, const uint32_t* seed, uint32_t site, float p_drop, void* stream) {
+  int rc = ln_check(dtype, M, d);
+  if (rc) return rc;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || !gamma2 || !beta2 || !y2 || !mean2 || !rstd2) return VCT_E_ARG;
+  const Ln2P n2 = {gamma2, beta2, y2, mean2, rstd2};
+  return add_ln_fwd_launch(dtype, M, d, x, res, gamma, beta, y, mean, rstd, seed, site, p_drop, n2, true, (hipStream_t)stream);
 }
 
 extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,

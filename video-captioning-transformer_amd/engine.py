@@ -303,15 +303,27 @@ class _StackBase:
     # with, so the unfused kernels stay the default; the fused block is kept (tested) for larger per-CU concurrency.
     fuse_attn_block = False
 
+    # out_proj + dropout + residual + LayerNorm as ONE row-complete launch (vct_linear_ln_fwd) behind the attention core.
+    # Measured at cfg-B: ALONE (tools/linear_ln_bench.py, recorded replays) it wins -- decoder rows 17.2 -> 13.8 us, encoder rows
+    # 14.0 -> 10.9 us per block -- but IN THE STEP it does not: same-box A/B 2.432 (unfused) vs 2.443 ms (fused), twice; the
+    # kernel's profile time there is 20.6 us against 12.7 alone.  One workgroup per CU with 136 KB of LDS shuts out whatever the
+    # other stream would co-schedule (the decoder prefix beside the encoder), like the 256-tile weight gradient did in round 2.
+    # The same kernel with linear2 (K = ff = 2048) loses even alone (36 vs 28 us: every workgroup streams the whole 2 MB weight
+    # at the L2 -> LDS rate of one CU).  Kept (tested) behind this switch, off.
+    fuse_out_ln = os.environ.get("VCT_FUSE_OUT_LN", "0") == "1"
+
     def _attn_ln_fwd(self, b, tag, ntag, lp, np_, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, site_ln, self_attn=True):
         """y = LayerNorm(x + dropout(out_proj(MHA(x, kv_src)))) of one attention block; saves o, a, mean, rstd for the
-        backward.  One fused launch behind the q/k/v projection GEMM(s) when the shape is covered
-        (ops.attn_block_supported), else attention core + out_proj GEMM + add-LayerNorm kernels."""
+        backward.  Behind the q/k/v projection GEMM(s): attention core, then out_proj + add-LayerNorm as one row-complete launch
+        (ops.linear_ln_fwd) when the shape is covered, else out_proj GEMM + add-LayerNorm kernels; or everything in one launch
+        (fuse_attn_block, off by default)."""
         d, H = self.cfg["d"], self.cfg["nhead"]
-        if not (self.fuse_attn_block and ops.attn_block_supported(self.dt, H, d // H, Lq, Lk)):
+        Mq = x.shape[0]
+        fuse_all = self.fuse_attn_block and ops.attn_block_supported(self.dt, H, d // H, Lq, Lk)
+        fuse_out = not fuse_all and self.fuse_out_ln and self.dev.type == "cuda" and ops.linear_ln_supported(self.dt, d, d)
+        if not (fuse_all or fuse_out):
             a = self._attn_block_fwd(b, tag, lp, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn=self_attn)
             return self._ln_fwd(b, ntag, np_, a, x, site_ln)
-        Mq = x.shape[0]
         if self_attn:
             qkv = b.get(tag + "qkv", (Mq, 3 * d), self.dt)
             ops.gemm(x, self.W(lp + "in_proj_weight"), qkv, bias=self.F(lp + "in_proj_bias"))
@@ -324,10 +336,14 @@ class _StackBase:
         o = b.get(tag + "o", (Mq, d), self.dt)
         a = b.get(tag + "a", (Mq, d), self.dt)
         y = b.get(ntag + "y", (Mq, d), self.dt)
+        mean, rstd = b.get(ntag + "mean", (Mq,), torch.float32), b.get(ntag + "rstd", (Mq,), torch.float32)
         drop = self.drop(site)
+        if fuse_out:
+            ops.attn_fwd(q, k, v, o, Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=drop)
+            return ops.linear_ln_fwd(o, self.W(lp + "out_proj.weight"), self.F(lp + "out_proj.bias"), x, self.F(np_ + "weight"),
+                                     self.F(np_ + "bias"), a, y, mean, rstd, dropout=self.drop(site_ln))
         return ops.attn_block_fwd(q, k, v, o, Bn, H, Lq, Lk, self.W(lp + "out_proj.weight"), self.F(lp + "out_proj.bias"), x,
-                                  self.F(np_ + "weight"), self.F(np_ + "bias"), a, y,
-                                  b.get(ntag + "mean", (Mq,), torch.float32), b.get(ntag + "rstd", (Mq,), torch.float32),
+                                  self.F(np_ + "weight"), self.F(np_ + "bias"), a, y, mean, rstd,
                                   causal=causal, key_pad=key_pad, dropout=drop, site_res=site_ln)
 
     def _cross_kv(self, b, tag, lp, mem):
@@ -392,6 +408,16 @@ class _StackBase:
         ops.add_ln_fwd(x, res, self.F(np_ + "weight"), self.F(np_ + "bias"), y, b.get(tag + "mean", (M,), torch.float32),
                        b.get(tag + "rstd", (M,), torch.float32), dropout=self.drop(site) if site is not None else None)
         return y
+
+    def _ln_ln_fwd(self, b, tag, np_, x, res, site, tag2, np2):
+        """The last layer's closing norm and the stack-final norm in one launch: returns (y, y2)."""
+        M, d = x.shape
+        y, y2 = b.get(tag + "y", (M, d), self.dt), b.get(tag2 + "y", (M, d), self.dt)
+        ops.add_ln_ln_fwd(x, res, self.F(np_ + "weight"), self.F(np_ + "bias"), y, b.get(tag + "mean", (M,), torch.float32),
+                          b.get(tag + "rstd", (M,), torch.float32), self.F(np2 + "weight"), self.F(np2 + "bias"), y2,
+                          b.get(tag2 + "mean", (M,), torch.float32), b.get(tag2 + "rstd", (M,), torch.float32),
+                          dropout=self.drop(site) if site is not None else None)
+        return y, y2
 
     def _ln_bwd(self, b, tag, np_, dy, x, res, site):
         """Returns (ds, dxo): gradient of the pre-norm sum and its dropout-masked copy.  The column
@@ -491,6 +517,10 @@ class EncoderEngine(_StackBase):
             x1 = self._attn_ln_fwd(b, tag + "sa.", tag + "n1.", lp + "self_attn.", lp + "norm1.", x, x, B, Te, Te, False, kpm,
                                    site + 1, site + 2)
             f = self._ffn_fwd(b, tag + "ff.", lp, x1, site + 3)
+            if l == L - 1:       # norm2 of the last layer + the stack-final norm: one launch
+                x, mem = self._ln_ln_fwd(b, tag + "n2.", lp + "norm2.", f, x1, site + 4, "nf.", "transformer_encoder.norm.")
+                b.t["x_last"] = x
+                return mem
             x = self._ln_fwd(b, tag + "n2.", lp + "norm2.", f, x1, site + 4)
         b.t["x_last"] = x
         return self._ln_fwd(b, "nf.", "transformer_encoder.norm.", x, None, None)
@@ -583,6 +613,11 @@ class DecoderEngine(_StackBase):
             x2 = self._attn_ln_fwd(b, tag + "ca.", tag + "n2.", lp + "multihead_attn.", lp + "norm2.", x1, mem, Bn, Sd, Te, False, None,
                                    site + 3, site + 4, self_attn=False)
             f = self._ffn_fwd(b, tag + "ff.", lp, x2, site + 5)
+            if l == L - 1:       # norm3 of the last layer + the stack-final norm: one launch
+                x, y = self._ln_ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, site + 6, "nf.", "decoder.norm.")
+                self._kv_prefetched = None
+                b.t["x_last"] = x
+                return y
             x = self._ln_fwd(b, tag + "n3.", lp + "norm3.", f, x2, site + 6)
         self._kv_prefetched = None
         b.t["x_last"] = x
@@ -691,7 +726,8 @@ class DecoderEngine(_StackBase):
                     self.flush_ln_grads(b)
                     bucket_ready("dec_layer", l)
                 self.flush_ln_grads(b)
-                ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
+                ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE),
+                              exclusive=self.exclusive_grads and bucket_ready is None)
                 if bucket_ready is not None:
                     bucket_ready("embedding")
                 if defer_gen_dw:
@@ -705,7 +741,8 @@ class DecoderEngine(_StackBase):
                 self.flush_ln_grads(b)
                 self.bucket_on_side(bucket_ready, "dec_layer", l)
         self.flush_ln_grads(b)
-        ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE))
+        ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE),
+                      exclusive=self.exclusive_grads and bucket_ready is None)
         if bucket_ready is not None:
             bucket_ready("embedding")
         if join:
@@ -920,6 +957,9 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # gained.)  Measured in the step (same box): the dX bracket drops 0.218 -> 0.181 ms and the Adam bracket grows by the 40 us of the
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
 DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "0") == "1"
+# set by trainer.CaptionTrainer (single GPU, fused optimizer): nothing but the backward schedule writes the flat gradient buffer,
+# so the token-embedding gradient only re-zeroes the rows it wrote in the previous step (ops.embed_bwd)
+DecoderEngine.exclusive_grads = False
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 

@@ -190,6 +190,39 @@ def attn_block_fwd(q, k, v, o, B, H, Lq, Lk, w_out, b_out, res, gamma, beta, a_o
     return y
 
 
+_ll_ok = {}
+
+
+def linear_ln_supported(dtype, d: int, K: int) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    r = _ll_ok.get((d, K))
+    if r is None:
+        r = _ll_ok[(d, K)] = bool(L.load().vct_linear_ln_supported(L.BF16, d, K))
+    return r
+
+
+def linear_ln_fwd(x, w, bias, res, gamma, beta, a_out, y, mean, rstd, dropout: Drop = None, ln2=None, rows_per_wg: int = 0):
+    """y = LayerNorm(res + dropout(x w^T + bias)) in one launch (include/vct_hip.h, vct_linear_ln_fwd); a_out receives the bf16
+    pre-dropout product (None: not saved).  ln2 = (gamma2, beta2, y2, mean2, rstd2): also y2 = LayerNorm2(y)."""
+    d = L.LinearLnDesc()
+    d.dtype, d.M, d.d, d.K = L.dtype_code(x.dtype), x.shape[0], w.shape[0], x.shape[1]
+    d.x, d.ldx, d.w, d.ldw, d.bias = x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), bias.data_ptr()
+    if res is not None:
+        d.res, d.ld_res = res.data_ptr(), _ld(res)
+    d.seed, d.site, d.p_drop = _drop(dropout)
+    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+    if a_out is not None:
+        d.a_out, d.ld_a = a_out.data_ptr(), _ld(a_out)
+    d.y, d.ld_y, d.mean, d.rstd = y.data_ptr(), _ld(y), mean.data_ptr(), rstd.data_ptr()
+    if ln2 is not None:
+        g2, b2, y2, m2, r2 = ln2
+        d.gamma2, d.beta2, d.y2, d.ld_y2, d.mean2, d.rstd2 = g2.data_ptr(), b2.data_ptr(), y2.data_ptr(), _ld(y2), m2.data_ptr(), r2.data_ptr()
+    d.rows_per_wg = rows_per_wg
+    L.check(L.load().vct_linear_ln_fwd(d, L.stream_ptr()), "vct_linear_ln_fwd")
+    return y
+
+
 def attn_bwd(q, k, v, d_o, dq, dk, dv, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
     hd = d_o.shape[1] // H
     d = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
@@ -205,6 +238,17 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, dropout: Drop = None):
                                     beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), s, site, p,
                                     L.stream_ptr()), "vct_add_ln_fwd")
     return y
+
+
+def add_ln_ln_fwd(x, res, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, dropout: Drop = None):
+    """y = LayerNorm(res + dropout(x)); y2 = LayerNorm2(y) -- a layer's last norm and the stack-final norm in one launch."""
+    M, dm = x.shape
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_add_ln_ln_fwd(L.dtype_code(x.dtype), M, dm, x.data_ptr(), L.ptr(res), gamma.data_ptr(), beta.data_ptr(),
+                                       y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(),
+                                       y2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), s, site, p, L.stream_ptr()),
+            "vct_add_ln_ln_fwd")
+    return y2
 
 
 def ln_ws_rows(M: int) -> int:
@@ -250,18 +294,28 @@ def embed_fwd(ids, S, table, pos, x, dropout: Drop = None):
 _embed_ws = {}
 
 
-def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None):
+def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, exclusive: bool = False):
+    """dtable fp32 [V, d] = deterministic scatter-add of the dx rows.  exclusive=True: the caller guarantees that nothing but
+    this function writes `dtable` between calls (the single-GPU fast training path: gradients are overwritten every step, never
+    accumulated or averaged in place) -- from the second exclusive call on, only the rows the previous call wrote are zeroed
+    (10 MB at cfg-B) instead of all V (62.5 MB).  Any non-exclusive call falls back to the full zero-fill and breaks the chain."""
     B = ids.shape[0]
     s, site, p = _drop(dropout)
     V = dtable.shape[0]
+    incremental = False
     if id_ws is None:
         key = (V, dx.device)
-        id_ws = _embed_ws.get(key)
-        if id_ws is None:
-            id_ws = _embed_ws[key] = torch.empty(2 * V, dtype=torch.int32, device=dx.device)
+        ent = _embed_ws.get(key)
+        if ent is None:      # [first_pos V | count V | dirty count 1 | dirty ids <= V]: never has to grow (recordings bake its address)
+            ent = _embed_ws[key] = [torch.zeros(3 * V + 1, dtype=torch.int32, device=dx.device), None]
+        id_ws = ent[0]
+        incremental = exclusive and ent[1] == dtable.data_ptr()
+        ent[1] = dtable.data_ptr() if exclusive else None
+    else:
+        assert id_ws.numel() >= 3 * V + 1
     L.check(L.load().vct_embed_bwd(L.dtype_code(dx.dtype), B, S, dx.shape[1], V, ids.data_ptr(),
-                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), id_ws.data_ptr(), s, site, p,
-                                   L.stream_ptr()), "vct_embed_bwd")
+                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), id_ws.data_ptr(), int(incremental),
+                                   s, site, p, L.stream_ptr()), "vct_embed_bwd")
 
 
 def sce_loss(logits, V, labels, S, pad_id, alpha, loss_out, dlogits, row_ws):
