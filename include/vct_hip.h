@@ -71,7 +71,8 @@ typedef struct vct_gemm_desc {
   float* bias_grad;                         /* optional [M] fp32: sum over K of op(A) (db for ta=1) */
   void* workspace; int64_t workspace_bytes; /* split-K partials (fp32); NULL = never split */
   int32_t split_k;                          /* 0 auto, 1 none, >1 forced */
-  int32_t reserved;
+  int32_t reserved;                         /* 0; kernel-selection override for tests / A-B probes: 1-9 (+10 x buffers) = a tile of
+                                               the general kernel, 100 = force / 99 = forbid the persistent-tile layer kernel */
   int32_t n_tile_counters;                  /* ints available at tile_counters */
   int32_t* tile_counters;                   /* optional, see below */
 } vct_gemm_desc;

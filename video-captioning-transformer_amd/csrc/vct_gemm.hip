@@ -318,8 +318,9 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   if (bf) {
     static const int cand[7][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {320, 128}, {64, 128}};
     int pick = 3;
-    const int tsel = d->reserved % 10;
-    pl.nbuf = (d->reserved / 10) ? (d->reserved / 10) : 2;
+    const int rsv = d->reserved >= 99 ? 0 : d->reserved;      // 99 / 100: persistent-tile kernel off / forced (vct_gemm_pt.hip)
+    const int tsel = rsv % 10;
+    pl.nbuf = (rsv / 10) ? (rsv / 10) : 2;
     const bool cover_ok = d->out_dtype == VCT_BF16 && d->ta == 0;      // the cover tiles exist for bf16-out NT / NN
     if (tsel == 5) { pick = 0; pl.waves8 = 1; }        // 128x128, 8 waves
     else if (tsel == 8) { pick = 1; pl.waves8 = 4; }   // 128x64, 8 waves
@@ -389,6 +390,7 @@ static int dispatch_layout(const vct_gemm_desc* d, const GemmP& p, int bm, dim3 
 int gemm_bf16_v2_dispatch(const vct_gemm_desc* d, const GemmP& p, int bm, int bn, int nbuf, dim3 grid, hipStream_t st);
 int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split);   // persistent 256x256 kernel (vct_gemm256.hip)
 int gemm_skinny_try(const vct_gemm_desc* d, hipStream_t st, bool* used);                    // M <= 256 rows (vct_gemm_skinny.hip)
+int gemm_pt_try(const vct_gemm_desc* d, hipStream_t st, bool* used);                        // persistent 128x128 tiles for the layer GEMMs (vct_gemm256.hip)
 
 }  // namespace vct
 
@@ -483,6 +485,12 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
       }
       return VCT_OK;
     }
+  }
+
+  {
+    bool used = false;
+    const int rcp = gemm_pt_try(d, st, &used);
+    if (rcp != VCT_OK || used) return rcp;
   }
 
   const int64_t need = vct_gemm_workspace_bytes(d);

@@ -46,29 +46,6 @@ struct G256P {
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
 };
 
-// instruction q (of R * 8 / (64 * NW) per wave) of dma_tile: one 1-KiB global_load_lds of an operand tile
-template <bool MC, int R, int NW>
-__device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext, int k0,
-                                          int wave, int lane, int q) {
-  const int ci = q * NW + wave;
-  const bf16_t* src;
-  if constexpr (!MC) {
-    const int row = ci * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (row & 7);
-    src = base + (long)min(r0 + row, r_ext - 1) * ld + k0 + c * 8;
-  } else {
-    constexpr int CPRW = R / 8, RPI = 64 / CPRW, NB = R / 16;
-    const int krow = ci * RPI + lane / CPRW;
-    const int pp = lane % CPRW;
-    const int b = (pp >> 1) ^ (krow & (NB - 1));
-    const int col = (b * 2 + (pp & 1)) * 8;
-    const int rlim = ((r_ext + 7) & ~7) - 8;
-    src = base + (long)(k0 + krow) * ld + min(r0 + col, rlim);
-  }
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
-}
-
 constexpr int G256_BM = 256, G256_BN = 256;
 constexpr int G256_STAGE = (G256_BM + G256_BN) * 128;              // bytes per K stage (64-deep): 64 KB
 constexpr int G256_LDS = 2 * G256_STAGE;                           // the epilogue's row slab lives in the stage that was just consumed
@@ -278,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
 // Persistent grid = the compute units the STREAM may use (one workgroup per CU, a multiple of 8 so that blockIdx & 7 stays the
 // XCD): 256 on an unmasked MI355X stream, fewer on a CU-masked one (vct_stream_create_masked) -- a 256-workgroup grid there
 // would queue two or more 128 KB-LDS workgroups behind each other on every allowed CU.  Looked up once per stream.
-static int g256_grid(hipStream_t st) {
+int persistent_grid(hipStream_t st) {
   static std::mutex mu;
   static std::unordered_map<void*, int> cache;
   std::lock_guard<std::mutex> lk(mu);
@@ -308,7 +285,7 @@ template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hi
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  vct::launch(gemm256_kernel<TA, TB, TO>, dim3(g256_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
+  vct::launch(gemm256_kernel<TA, TB, TO>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
@@ -328,7 +305,7 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   // (and tested) behind the mask.
   static const char* env = getenv("VCT_GEMM256");
   const int mask = env != nullptr ? atoi(env) : 11;
-  if (mask == 0 || d->dtype != VCT_BF16 || d->reserved != 0) return VCT_OK;
+  if (mask == 0 || d->dtype != VCT_BF16 || (d->reserved != 0 && d->reserved < 99)) return VCT_OK;
   if (d->act != VCT_ACT_NONE || d->preact || d->addend || d->dact_src || (d->seed && d->p_drop > 0.0f)) return VCT_OK;
   const int form = d->ta * 2 + d->tb;                         // 1 NT, 0 NN, 2 TN
   if (d->K < 256) return VCT_OK;

@@ -74,6 +74,29 @@ __device__ __forceinline__ void dma_tile(unsigned char* lds, const bf16_t* __res
   }
 }
 
+// instruction q (of R * 8 / (64 * NW) per wave) of dma_tile: one 1-KiB global_load_lds of an operand tile
+template <bool MC, int R, int NW>
+__device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext, int k0,
+                                          int wave, int lane, int q) {
+  const int ci = q * NW + wave;
+  const bf16_t* src;
+  if constexpr (!MC) {
+    const int row = ci * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    src = base + (long)min(r0 + row, r_ext - 1) * ld + k0 + c * 8;
+  } else {
+    constexpr int CPRW = R / 8, RPI = 64 / CPRW, NB = R / 16;
+    const int krow = ci * RPI + lane / CPRW;
+    const int pp = lane % CPRW;
+    const int b = (pp >> 1) ^ (krow & (NB - 1));
+    const int col = (b * 2 + (pp & 1)) * 8;
+    const int rlim = ((r_ext + 7) & ~7) - 8;
+    src = base + (long)(k0 + krow) * ld + min(r0 + col, rlim);
+  }
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
+}
+
 // ragged last K tile: predicated 16-byte loads (zero fill) written into the same swizzled image
 struct alignas(16) V16b { uint32_t w[4]; };
 template <bool MC, int R, int NT>

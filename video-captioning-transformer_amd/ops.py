@@ -78,7 +78,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
          addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
          bias_grad: Optional[torch.Tensor] = None, workspace=None, split_k: int = 0,
          n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None,
-         tag: Optional[str] = None) -> torch.Tensor:
+         tag: Optional[str] = None, tile: int = 0) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
     tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
     logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns).
@@ -86,6 +86,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
     lib = L.load()
     d = _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
                    n_valid, k_valid, m_valid)
+    d.reserved = tile       # kernel selection override (include/vct_hip.h, vct_gemm_desc.reserved): tests and A/B probes
     timed = _taps_on and tag in TAPS and (_taps_only is None or tag in _taps_only)
     if timed:
         tap(tag, 0)
