@@ -379,6 +379,37 @@ int vct_decode_linear(const vct_decode_linear_desc* d, void* stream);
 int vct_decode_ln2(int M, int K, const float* x, int64_t ldx, const float* g1, const float* b1, const float* g2, const float* b2,
                    void* y, int64_t ldy, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batch-1 greedy-decode step, one launch per BLOCK of a decoder layer (csrc/vct_decode_block.hip; bf16 weights, fp32 vectors):
+ *   kind 0  self-attention block   x -> q|k|v of the new token (-> cache slot), attention over Lk cached keys (the last one is
+ *                                  the new token), PARTIAL out-projection per head: part_out[h][d]
+ *   kind 1  cross-attention block  x1 -> q, attention over the memory's Lk cached K/V rows, partial out-projection per head
+ *   kind 2  feed-forward block     x2 -> act(W1 x2 + b1) per 64 hidden units, partial linear2 per unit group: part_out[ff/64][d]
+ *   kind 3  generator              y -> logits fp32 [V] (part_out)
+ * The input vector of every launch is built by each workgroup: the embedded token (id / table / pos_row) or
+ * res + res_bias + sum_c part[c] (the previous block's residual, the bias of its second product, its partial vectors),
+ * followed by LayerNorm(g1, b1) and LayerNorm(g2, b2) when given; x_out receives it (the next block's residual).
+ * replaces: CapDecoder.decode_word for one caption (model/CapDecoder.py:62-79; torch nn/modules/transformer.py:1143-1199) --
+ * 3 launches per layer instead of the 6 of vct_decode_gemv.  w_a / b_a: the first product's weight rows [*, d] and bias
+ * (in_proj | q rows | linear1 | generator); w_b: the second product's weight TRANSPOSED, [*, d] = [in, out] (out_proj^T |
+ * linear2^T: a workgroup's 64 input columns are then 64 contiguous rows).
+ * vct_decode_block_supported: bf16, d = 512 with head_dim 64 (8 heads), ff a multiple of 64 (<= 2048), Lk <= 64.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_decode_block_desc {
+  int32_t kind, d, ff, V, Lk, act;
+  const int64_t* id; const float* table; const float* pos_row;
+  const float* res; const float* res_bias; const float* part; int32_t n_part, pad0;
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  float* x_out;
+  const void* w_a; int64_t ld_a; const float* b_a;
+  void* slot;
+  const void* kc; const void* vc; int64_t kv_ld;
+  const void* w_b; int64_t ld_b;
+  float* part_out;
+} vct_decode_block_desc;
+int vct_decode_block_supported(int dtype, int d, int H, int ff, int Lk);
+int vct_decode_block(const vct_decode_block_desc* d, void* stream);
+
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);
 

@@ -180,13 +180,16 @@ def test_cfgB_greedy_decode_batch128_vs_oracle():
     assert n > 0.9 * ref_ys.size
 
 
-@pytest.mark.parametrize("B", [1, 16, 128])
-def test_cfgB_bf16_kv_cache_step_teacher_forced(B):
+@pytest.mark.parametrize("B,path", [(1, "block"), (1, "gemv"), (16, "skinny"), (128, "skinny")])
+def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
     """The bf16 token step that bench.py times -- batch 1: weight-streaming matrix-vector kernels (vct_decode_gemv), batch >= 2:
     skinny MFMA projections with LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
     caption: the predicted next id must be the reference's wherever its top-2 logit margin is resolvable in bf16 (> 0.15),
-    over >= 9 positions.  Batch 1 / 16: ids and margins recorded from the reference (cfgB_decode.npz); batch 128: the oracle."""
+    over >= 9 positions.  Batch 1 / 16: ids and margins recorded from the reference (cfgB_decode.npz); batch 128: the oracle.
+    Batch 1 runs both of its kernels: one launch per layer block (vct_decode_block, the default) and one per stage (vct_decode_gemv)."""
     from vct_amd import decode, engine
+    if path == "gemv":
+        monkeypatch.setattr(engine.DecoderEngine, "block_decode", False)
     z = load_golden("cfgB_decode.npz")
     mc, V = model_config_of(z), int(z["vocab"])
     cfg = O.cfg_from_model_config(mc, V)
@@ -204,8 +207,8 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B):
     mb.eval()
     dec = mb.cap_decoder._engine()
     st = engine.DecodeState(dec, B, 13, steps + 1)
-    if B == 1:
-        assert engine._decoder_small_decode_ok(dec, st)            # the path under test is the one that runs
+    if B == 1:                                                     # the path under test is the one that runs
+        assert engine._decoder_block_decode_ok(dec, st) == (path == "block") and engine._decoder_small_decode_ok(dec, st)
     else:
         assert engine._decoder_fused_decode_ok(dec, st) and not engine._decoder_small_decode_ok(dec, st)
     feats = torch.from_numpy(f).to(DEV)

@@ -67,6 +67,13 @@ class DecodeLinearDesc(C.Structure):
                 ("ids", vp), ("id_stride", i64)]
 
 
+class DecodeBlockDesc(C.Structure):
+    _fields_ = [("kind", i32), ("d", i32), ("ff", i32), ("V", i32), ("Lk", i32), ("act", i32),
+                ("id", vp), ("table", vp), ("pos_row", vp), ("res", vp), ("res_bias", vp), ("part", vp), ("n_part", i32), ("pad0", i32),
+                ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("x_out", vp), ("w_a", vp), ("ld_a", i64), ("b_a", vp), ("slot", vp),
+                ("kc", vp), ("vc", vp), ("kv_ld", i64), ("w_b", vp), ("ld_b", i64), ("part_out", vp)]
+
+
 DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}
 
 _SIGS = {
@@ -96,6 +103,8 @@ _SIGS = {
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),
     "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
+    "vct_decode_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vct_decode_block": (C.c_int, [C.POINTER(DecodeBlockDesc), vp]),
     "vct_decode_linear": (C.c_int, [C.POINTER(DecodeLinearDesc), vp]),
     "vct_decode_ln2": (C.c_int, [C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),

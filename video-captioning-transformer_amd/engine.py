@@ -183,6 +183,7 @@ class _StackBase:
 
     # parameter access: compute-dtype weight, fp32 vector, fp32 gradient
     def W(self, k): return self.ps.c[self.pre + k]
+    def WT(self, k): return self.ps.want_transposed(self.pre + k)      # [in, out] copy, kept in step with the shadow
     def F(self, k): return self.ps.params[self.pre + k].data
     def G(self, k): return self.ps.g[self.pre + k]
 
@@ -687,8 +688,15 @@ class DecoderEngine(_StackBase):
         # is DEFERRED to the end of the main stream's tail, where that stream would otherwise idle -- beside the decoder's
         # dX chain it slowed the critical path (a 34 us GEMM took 123 us next to it)
         defer_gen_dw = self.defer_gen_dw and bucket_ready is None and on_dmem_ready is not None
+        early_gen_dw = self.early_gen_dw and bucket_ready is None and on_dmem_ready is not None
+        if early_gen_dw:      # A/B: right behind the dX GEMM on the main stream, alone on the chip (nothing runs on the side stream yet)
+            defer_gen_dw = False
+            ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
+                     tag="gen_dw", workspace=self.gemm_ws())
 
         def gen_dw():
+            if early_gen_dw:
+                return
             if defer_gen_dw:
                 ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
                          tag="gen_dw", workspace=self.gemm_ws())
@@ -887,6 +895,52 @@ def _decoder_decode_step_small(self, st: DecodeState, t: int, end_id: int):
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
+def _decoder_block_decode_ok(self, st: DecodeState) -> bool:
+    """The batch-1 step with one launch per layer BLOCK (ops.decode_block): bf16, head_dim 64, d = 512 / 1024, <= 64 positions."""
+    d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
+    return (self.block_decode and st.B == 1 and self.dev.type == "cuda" and st.Lmax <= 64 and st.Te <= 64
+            and ops.decode_block_supported(self.dt, d, H, ff, min(st.Lmax, 64)))
+
+
+def _decoder_decode_step_block(self, st: DecodeState, t: int, end_id: int):
+    """The step of _decoder_decode_step for ONE caption in 3 launches per layer + 2: self-attention block, cross-attention block,
+    feed-forward block (each: first product + attention / activation + the second product split over the workgroups that own the
+    first, as partial vectors), generator, arg-max.  The partial vectors, the residual, the second product's bias and the
+    LayerNorm(s) are folded by the prologue of the next launch (csrc/vct_decode_block.hip)."""
+    d, H, L, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.Te, st.Lmax, self.cfg["ff"]
+    b = st.b
+    f32 = torch.float32
+    xa, x1, x2 = b.get("kx", (d,), f32), b.get("kx1", (d,), f32), b.get("kx2", (d,), f32)
+    a_part, c_part, f_part = b.get("ka", (H, d), f32), b.get("kc", (H, d), f32), b.get("kf", (ff // 64, d), f32)
+    prev = None                                   # (bias of linear2, norm3) of the layer below
+    for l in range(L):
+        lp = f"decoder.layers.{l}."
+        sa, ca = lp + "self_attn.", lp + "multihead_attn."
+        cache = st.kv_self[l]                                              # [Lmax, 3d]: q | k | v of every consumed token
+        slot = cache[t - 1]
+        src = (dict(embed=(st.ys[0, t - 1:t], self.F("tgt_to_emb.weight"), self.pos[t - 1])) if prev is None else
+               dict(res=x2, res_bias=prev[0], part=f_part, ln1=prev[1]))
+        ops.decode_block("self", d, w_a=self.W(sa + "in_proj_weight"), b_a=self.F(sa + "in_proj_bias"), slot=slot,
+                         kc=cache[:, d:2 * d], vc=cache[:, 2 * d:], kv_ld=3 * d, Lk=t, w_b=self.WT(sa + "out_proj.weight"),
+                         part_out=a_part, x_out=xa, **src)
+        kvc = st.kv_cross[l]                                               # [Te, 2d]
+        ops.decode_block("cross", d, res=xa, res_bias=self.F(sa + "out_proj.bias"), part=a_part,
+                         ln1=(self.F(lp + "norm1.weight"), self.F(lp + "norm1.bias")), x_out=x1,
+                         w_a=self.W(ca + "in_proj_weight")[:d], b_a=self.F(ca + "in_proj_bias")[:d], kc=kvc[:, :d], vc=kvc[:, d:],
+                         kv_ld=2 * d, Lk=Te, w_b=self.WT(ca + "out_proj.weight"), part_out=c_part)
+        ops.decode_block("ffn", d, res=x1, res_bias=self.F(ca + "out_proj.bias"), part=c_part,
+                         ln1=(self.F(lp + "norm2.weight"), self.F(lp + "norm2.bias")), x_out=x2,
+                         w_a=self.W(lp + "linear1.weight"), b_a=self.F(lp + "linear1.bias"), w_b=self.WT(lp + "linear2.weight"),
+                         ff=ff, act=self.cfg["activation"], part_out=f_part)
+        prev = (self.F(lp + "linear2.bias"), (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias")))
+    logits = b.get("klogits", (1, self.Vp), f32)
+    ops.decode_block("gen", d, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1],
+                     ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), w_a=self.W("generator.weight"),
+                     b_a=self.F("generator.bias"), V=self.V, part_out=logits)
+    st.last_logits = logits
+    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
+
+
 def _decoder_fused_decode_ok(self, st: DecodeState) -> bool:
     """The batched step with LayerNorms folded into the consuming projections (ops.decode_linear): bf16, up to 256 captions in
     flight, model width <= 1024 (a row's statistics come out of one pass over the MFMA fragments)."""
@@ -944,6 +998,8 @@ def _decoder_decode_step_fused(self, st: DecodeState, t: int, end_id: int):
 
 
 def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
+    if _decoder_block_decode_ok(self, st):
+        return _decoder_decode_step_block(self, st, t, end_id)
     if _decoder_small_decode_ok(self, st):
         return _decoder_decode_step_small(self, st, t, end_id)
     if _decoder_fused_decode_ok(self, st):
@@ -957,12 +1013,14 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # gained.)  Measured in the step (same box): the dX bracket drops 0.218 -> 0.181 ms and the Adam bracket grows by the 40 us of the
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
 DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "0") == "1"
+DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
 # set by trainer.CaptionTrainer (single GPU, fused optimizer): nothing but the backward schedule writes the flat gradient buffer,
 # so the token-embedding gradient only re-zeroes the rows it wrote in the previous step (ops.embed_bwd)
 DecoderEngine.exclusive_grads = False
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 
+DecoderEngine.block_decode = os.environ.get("VCT_BLOCK_DECODE", "1") != "0"   # A/B switch: 3 launches per layer at batch 1 (bf16)
 DecoderEngine.small_batch_decode = True       # A/B switch: weight-streaming GEMV step for batch <= 4
 DecoderEngine.decode_begin = _decoder_decode_begin
 DecoderEngine.decode_step = _decoder_decode_step_any

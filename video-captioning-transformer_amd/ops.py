@@ -399,6 +399,44 @@ def decode_gemv(W, out, B, *, bias=None, pro="none", x_in=None, ln1=None, ln2=No
     L.check(L.load().vct_decode_gemv(d, L.stream_ptr()), "vct_decode_gemv")
 
 
+def decode_block(kind: str, d: int, *, w_a, b_a, part_out, embed=None, res=None, res_bias=None, part=None, ln1=None, ln2=None, x_out=None,
+                 slot=None, kc=None, vc=None, kv_ld=0, Lk=1, w_b=None, ff=0, act=None, V=0):
+    """One block of the batch-1 greedy-decode step (include/vct_hip.h, vct_decode_block): kind in {'self', 'cross', 'ffn', 'gen'}.
+    embed = (id view [1] int64, table fp32 [V, d], pos_row fp32 [d]) or the vector res + res_bias + sum(part) (fp32 [d] / [n, d])."""
+    q = L.DecodeBlockDesc()
+    q.kind, q.d, q.ff, q.V, q.Lk, q.act = {"self": 0, "cross": 1, "ffn": 2, "gen": 3}[kind], d, ff, V, Lk, L.ACT[act]
+    if embed is not None:
+        ids, table, pos_row = embed
+        q.id, q.table, q.pos_row = ids.data_ptr(), table.data_ptr(), pos_row.data_ptr()
+    q.res, q.res_bias = L.ptr(res), L.ptr(res_bias)
+    if part is not None:
+        q.part, q.n_part = part.data_ptr(), part.shape[0]
+    if ln1 is not None:
+        q.g1, q.b1 = ln1[0].data_ptr(), ln1[1].data_ptr()
+    if ln2 is not None:
+        q.g2, q.b2 = ln2[0].data_ptr(), ln2[1].data_ptr()
+    q.x_out = L.ptr(x_out)
+    q.w_a, q.ld_a, q.b_a = w_a.data_ptr(), _ld(w_a), b_a.data_ptr()
+    q.slot, q.kc, q.vc, q.kv_ld = L.ptr(slot), L.ptr(kc), L.ptr(vc), kv_ld
+    if w_b is not None:
+        q.w_b, q.ld_b = w_b.data_ptr(), _ld(w_b)
+    q.part_out = part_out.data_ptr()
+    L.check(L.load().vct_decode_block(q, L.stream_ptr()), "vct_decode_block")
+
+
+_db_ok = {}
+
+
+def decode_block_supported(dtype, d: int, H: int, ff: int, Lk: int) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    key = (d, H, ff, Lk)
+    r = _db_ok.get(key)
+    if r is None:
+        r = _db_ok[key] = bool(L.load().vct_decode_block_supported(L.BF16, d, H, ff, Lk))
+    return r
+
+
 def transpose(src: torch.Tensor, dst: torch.Tensor):
     """dst[c, r] = src[r, c] (bf16; row strides free)."""
     L.check(L.load().vct_transpose(L.dtype_code(src.dtype), src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
