@@ -290,6 +290,11 @@ int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
                   const float* hyper_dev, void* stream);
+/* The same step over ONE 2-D weight [rows, cols] (cols a multiple of 64; contiguous) that also writes its TRANSPOSED bf16 shadow
+ * shadow_t [cols][ld_t >= rows] -- W_g^T for the NT form of the vocabulary dX -- in the same pass (no step-counter bump). */
+int vct_adam_step_2d(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                     void* shadow_t_bf16, int32_t rows, int32_t cols, int64_t ld_t, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int32_t* step_dev, const float* hyper_dev, void* stream);
 
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */

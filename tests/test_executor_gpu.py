@@ -342,3 +342,35 @@ def test_replay_follows_weights_loaded_outside_the_optimizer(executor):
     l0, p0 = run("eager")
     l1, p1 = run(executor)
     assert torch.equal(l0, l1) and torch.equal(p0, p1)
+
+
+def test_decode_after_training_steps_uses_the_current_weights():
+    """The batch-1 decode kernels read TRANSPOSED copies of out_proj / linear2 that are refreshed on demand (not by every optimizer
+    step): decoding, training a few recorded steps, decoding again must equal a fresh model loaded with the trained weights --
+    with the captured token-step graphs of the first call still in use."""
+    from helpers import build_model
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    mc = dict(MC, embed_dim=512, modal_shape=[48])
+    mc["video_encoder"] = dict(mc["video_encoder"], layer=1, nhead=8, feedforward=256)
+    mc["caption_decoder"] = dict(mc["caption_decoder"], layer=2, nhead=8, feedforward=256)
+    torch.manual_seed(5)
+    m = build_model(mc, VOCAB, DEV, torch.bfloat16)
+    feats = torch.randn(1, 7, 48, generator=torch.Generator().manual_seed(1)).to(DEV)
+    from vct_amd import engine
+    ys0 = m.greedy_decode_ids([feats], None, max_len=8)
+    st = next(iter(m.__dict__["_decode_sessions"].values()))
+    assert engine._decoder_block_decode_ok(m.cap_decoder._engine(), st)          # the transposed-weight path is the one in use
+    m.train()
+    tr = CaptionTrainer(m, FusedAdam(m, lr=5e-2), launch_list=True)
+    for k in range(4):
+        tr.step(*_batch(300 + k))
+    torch.cuda.synchronize()
+    ys1 = m.greedy_decode_ids([feats], None, max_len=8)
+    ref = build_model(mc, VOCAB, DEV, torch.bfloat16)
+    ref.load_state_dict(m.state_dict())
+    ys_ref = ref.greedy_decode_ids([feats], None, max_len=8)
+    assert torch.equal(ys1, ys_ref)
+    for name, ent in m._ps.transposed.items():
+        if not ent[3]:
+            w = m._ps.c[name]
+            assert torch.equal(ent[0][:, :w.shape[0]], w.t()), name

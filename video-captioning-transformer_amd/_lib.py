@@ -111,6 +111,7 @@ _SIGS = {
     "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp]),
+    "vct_adam_step_2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
     "vct_cmdlist_create": (C.c_int, [C.POINTER(vp)]),
     "vct_cmdlist_destroy": (C.c_int, [vp]),
     "vct_cmdlist_begin": (C.c_int, [vp, vp]),

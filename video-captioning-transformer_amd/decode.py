@@ -21,6 +21,7 @@ from .utils import capture_graph
 def greedy_decode_ids_reference_algorithm(model, feats: torch.Tensor, mask, max_len: int = 30) -> torch.Tensor:
     pre = model.cap_preprocessor
     model._ps.refresh_shadow()
+    model._ps.refresh_lazy_transposed()
     enc, dec = model.video_encoder._engine(), model.cap_decoder._engine()
     B, T = feats.shape[0], feats.shape[1]
     mem = enc.forward(feats, mask, False)
@@ -60,6 +61,7 @@ def greedy_decode_ids(model, feats: torch.Tensor, mask, max_len: int = 30, use_g
     caption batch that ends at step s therefore costs at most s + lookahead steps; the id matrix is truncated at s."""
     pre = model.cap_preprocessor
     model._ps.refresh_shadow()
+    model._ps.refresh_lazy_transposed()
     enc, dec = model.video_encoder._engine(), model.cap_decoder._engine()
     B, T = feats.shape[0], feats.shape[1]
     st = _session(model, dec, B, T + 1, max_len)
@@ -149,6 +151,7 @@ def teacher_forced_next_ids(model, feats: torch.Tensor, mask, prefix_ids: torch.
     [B, steps, V] of every step."""
     pre = model.cap_preprocessor
     model._ps.refresh_shadow()
+    model._ps.refresh_lazy_transposed()
     enc, dec = model.video_encoder._engine(), model.cap_decoder._engine()
     B, T = feats.shape[0], feats.shape[1]
     st = DecodeState(dec, B, T + 1, steps + 1)

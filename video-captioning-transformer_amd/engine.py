@@ -71,6 +71,7 @@ class ParamSet:
             self.cflat = torch.zeros(self.total, dtype=compute_dtype, device=device)
             self.c = {n: self.cflat[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape) for n, p in named}
         self._stamp = None
+        self.version = 0        # bumped whenever the shadow is (or may have been) rewritten: lazy transposed copies key on it
         # transposed copies of individual weight matrices in the compute dtype (name -> (tensor [cols, ld], start, end)): kept in
         # step with the shadow by refresh_shadow / cast_range / FusedAdam.step_range (refresh_transposed)
         self.transposed = {}
@@ -103,6 +104,7 @@ class ParamSet:
                 return
         for a, b in self.cast_ranges:
             ops.cast(self.flat[a:b], self.cflat[a:b])
+        self.version += 1
         self.refresh_transposed(0, self.total)
         self._stamp = stamp if stamp is not None else sum(p._version for p in self.params.values())
 
@@ -114,25 +116,49 @@ class ParamSet:
             lo, hi = max(a, x), min(b, y)
             if hi > lo:
                 ops.cast(self.flat[lo:hi], self.cflat[lo:hi])
+        self.version += 1
         self.refresh_transposed(a, b)
 
-    def want_transposed(self, name: str) -> torch.Tensor:
-        """A [cols, ld >= rows] transposed copy (compute dtype) of the 2-D weight `name`, created on first use and from then on
-        rewritten whenever the shadow of that weight is (the whole matrix must lie inside the refreshed range)."""
+    def want_transposed(self, name: str, eager: bool = False) -> torch.Tensor:
+        """A [cols, ld >= rows] transposed copy (compute dtype) of the 2-D weight `name`, created on first use.
+        eager=True (a training-step operand: W_g^T of the NT-form vocabulary dX): rewritten whenever the shadow of that weight
+        is -- by the optimizer's own pass when it is FusedAdam (vct_adam_step_2d), else by a transpose launch behind it.
+        eager=False (decode-time operands): refreshed HERE, on demand, when the shadow has changed since the copy was made
+        (`version` counts shadow rewrites): a training loop that validates between epochs pays nothing per step for them."""
         ent = self.transposed.get(name)
         if ent is None:
             w = self.c[name]
             rows, cols = w.shape
             t = torch.zeros(cols, (rows + 31) // 32 * 32, dtype=w.dtype, device=w.device)
             a = self.offsets[name]
-            ent = self.transposed[name] = (t, a, a + w.numel())
-            ops.transpose(w, t)
+            ent = self.transposed[name] = [t, a, a + w.numel(), bool(eager), -1]
+        was_lazy = not ent[3]
+        if eager:
+            ent[3] = True
+        if ent[4] != self.version:
+            if ent[4] < 0 or was_lazy:                # new, or a (so far) lazy copy that is out of date
+                ops.transpose(self.c[name], ent[0])
+            ent[4] = self.version
         return ent[0]
 
-    def refresh_transposed(self, a: int, b: int):
-        for name, (t, x, y) in self.transposed.items():
-            if a <= x and y <= b:
-                ops.transpose(self.c[name], t)
+    def refresh_lazy_transposed(self):
+        """Bring every on-demand transposed copy up to date (decode entry points call this before replaying captured steps,
+        which bake the copies' addresses but cannot notice that the weights moved on)."""
+        for name, ent in self.transposed.items():
+            if not ent[3] and ent[4] != self.version:
+                ops.transpose(self.c[name], ent[0])
+                ent[4] = self.version
+
+    def refresh_transposed(self, a: int, b: int, skip=()):
+        """Shadow elements [a, b) were just rewritten: eager transposed copies inside follow (except `skip`: already written by
+        the optimizer's fused pass); lazy ones are picked up by want_transposed through `version`."""
+        for name, ent in self.transposed.items():
+            if ent[3] and name not in skip and a <= ent[1] and ent[2] <= b:
+                ops.transpose(self.c[name], ent[0])
+
+    def eager_transposed_in(self, a: int, b: int):
+        """[(name, tensor, start, end)] of the eager transposed copies whose weight lies inside flat elements [a, b)."""
+        return [(n, e[0], e[1], e[2]) for n, e in self.transposed.items() if e[3] and a <= e[1] and e[2] <= b]
 
     def install_grads(self):
         for n, p in self.params.items():
@@ -641,7 +667,7 @@ class DecoderEngine(_StackBase):
             # dX = dlogits W_g in the K-contiguous NT form (persistent 256x256 kernel, split over K): needs W_g^T, which the
             # parameter set keeps beside the bf16 shadow -- rewritten right after the optimizer has touched W_g (62 MB of traffic
             # in the main stream's slack at the end of the step), not here in front of the latency-bound layer stack
-            self._wgt = self.ps.want_transposed(self.pre + "generator.weight")
+            self._wgt = self.ps.want_transposed(self.pre + "generator.weight", eager=True)
         y = self._run_stack(b, mem, Bn, Te, ids, Sd, kpm)
         ops.tap("layers_fwd", 1)
         logits = b.get("logits", (M, self.Vp), self.dt)
@@ -1012,7 +1038,7 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # stream's slack at the end of the step.  (Rebuilt in front of the layer stack at every step it cost the forward more than the dX
 # gained.)  Measured in the step (same box): the dX bracket drops 0.218 -> 0.181 ms and the Adam bracket grows by the 40 us of the
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
-DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "0") == "1"
+DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "1") != "0"
 DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
 # set by trainer.CaptionTrainer (single GPU, fused optimizer): nothing but the backward schedule writes the flat gradient buffer,
 # so the token-embedding gradient only re-zeroes the rows it wrote in the previous step (ops.embed_bwd)

@@ -358,6 +358,16 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, w
             "vct_adam_step")
 
 
+def adam_step_2d(param, grad, exp_avg, exp_avg_sq, shadow, shadow_t, lr, beta1, beta2, eps, weight_decay, step_dev, hyper=None):
+    """vct_adam_step on one 2-D weight (views [rows, cols] of the flat buffers) that also writes the transposed bf16 shadow
+    shadow_t [cols, ld >= rows] in the same pass."""
+    rows, cols = param.shape
+    L.check(L.load().vct_adam_step_2d(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
+                                      shadow_t.data_ptr(), rows, cols, shadow_t.stride(0), float(lr), float(beta1), float(beta2),
+                                      float(eps), float(weight_decay), step_dev.data_ptr(), L.ptr(hyper), L.stream_ptr()),
+            "vct_adam_step_2d")
+
+
 def adam_bump(step_dev):
     L.check(L.load().vct_adam_step(step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), step_dev.data_ptr(), 0, 0,
                                    0.0, 0.0, 0.0, 0.0, 0.0, step_dev.data_ptr(), 0, 0, 1, 0, L.stream_ptr()), "vct_adam_step(bump)")

@@ -228,17 +228,35 @@ class FusedAdam(torch.optim.Optimizer):
             return
         lr, b1, b2, eps, wd = self._hyper_now()
         ps = self.model._ps
-        shadow = ps.cflat[a:b] if ps.compute_dtype != torch.float32 else None
-        s0, s1 = max(self.skip[0], a) - a, min(self.skip[1], b) - a
-        ops.adam_step(ps.flat[a:b], ps.gflat[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], shadow, lr, b1, b2, eps, wd,
-                      self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper)
-        if shadow is not None:
-            ps.refresh_transposed(a, b)          # transposed weight copies follow the shadow this kernel has just rewritten
+        bf = ps.compute_dtype != torch.float32
+        # 2-D weights with an eager transposed shadow inside the range (W_g^T): their own pass writes the transposed copy too
+        fused = sorted(ps.eager_transposed_in(a, b), key=lambda x: x[2]) if bf else []
+        fused = [f for f in fused if ps.params[f[0]].shape[1] % 64 == 0 and not (f[2] < self.skip[1] and f[3] > self.skip[0])]
+
+        def flat_range(lo, hi):
+            if hi <= lo:
+                return
+            shadow = ps.cflat[lo:hi] if bf else None
+            s0, s1 = max(self.skip[0], lo) - lo, min(self.skip[1], hi) - lo
+            ops.adam_step(ps.flat[lo:hi], ps.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], shadow, lr, b1, b2, eps, wd,
+                          self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper)
+        cur = a
+        for name, t, x, y in fused:
+            flat_range(cur, x)
+            shape = ps.params[name].shape
+            ops.adam_step_2d(ps.flat[x:y].view(shape), ps.gflat[x:y].view(shape), self.exp_avg[x:y].view(shape),
+                             self.exp_avg_sq[x:y].view(shape), ps.cflat[x:y].view(shape), t, lr, b1, b2, eps, wd, self.step_dev,
+                             hyper=self.hyper)
+            cur = y
+        flat_range(cur, b)
+        if bf:
+            ps.refresh_transposed(a, b, skip=[f[0] for f in fused])   # other eager copies follow the shadow this pass rewrote
 
     @torch.no_grad()
     def finish_ranges(self):
         ops.adam_bump(self.step_dev)
         ps = self.model._ps
+        ps.version += 1
         ps._stamp = sum(p._version for p in ps.params.values())
 
     def zero_grad(self, set_to_none: bool = True):
@@ -474,6 +492,7 @@ class CaptionTrainer:
                 return eager_loss
             self._fresh_shadow()
             ll[0].replay()
+            self.model._ps.version += 1          # the replayed optimizer rewrote the shadow (lazy transposed copies key on this)
             return ll[1]
         g = self._graphs.get(key)
         if g is None:
@@ -495,6 +514,7 @@ class CaptionTrainer:
         graph, loss = g
         self._fresh_shadow()
         graph.replay()
+        self.model._ps.version += 1
         return loss
 
 
