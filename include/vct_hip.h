@@ -236,17 +236,17 @@ int vct_enc_frontend_bwd(int dtype, int B, int T, int d, const void* dz, void* d
  * ids: int64 [N] read with element stride id_stride from ids + b*id_batch_stride (so the token-shift
  * view tgt[:, :-1] needs no copy): token n = (b = n / S, s = n % S) -> ids[b*id_batch_stride + s].
  * bwd: dtable fp32 [V,d] = scatter-add of dx rows (deterministic order), row pad_id zero.
- *      id_ws: int32 [3*V + 1] scratch: first-occurrence / count tables (built with integer atomics) and the list of
- *      table rows this call wrote.  incremental != 0: dtable is known to be zero outside the rows the PREVIOUS call (same
- *      dtable, same id_ws, nothing else writing dtable in between) listed there, so only those rows are zeroed (10 MB instead
+ *      id_ws: int32 [id_ws_ints >= 2*V + 4 + B*S] scratch: first-occurrence / count tables (built with integer atomics) and the
+ *      batch's ids in position order, which the NEXT call reads.  incremental != 0: dtable is known to be zero outside the rows of the ids of the PREVIOUS call (same
+ *      dtable, same id_ws, nothing else writing dtable in between), so only those rows are zeroed (10 MB instead
  *      of 62.5 MB at cfg-B); incremental == 0 zeroes all V rows.
  * --------------------------------------------------------------------------------------------- */
 int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids, int64_t id_batch_stride,
                   const void* table, const float* pos, void* x, const uint32_t* seed, uint32_t site,
                   float p_drop, void* stream);
 int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                  int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int incremental, const uint32_t* seed,
-                  uint32_t site, float p_drop, void* stream);
+                  int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int64_t id_ws_ints, int incremental,
+                  const uint32_t* seed, uint32_t site, float p_drop, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Symmetric cross-entropy loss + gradient w.r.t. logits, one workgroup per row, row held in registers

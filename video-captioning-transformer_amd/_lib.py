@@ -97,7 +97,7 @@ _SIGS = {
     "vct_enc_frontend_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "vct_enc_frontend_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "vct_embed_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, u32, f32, vp]),
-    "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, C.c_int, vp, u32, f32, vp]),
+    "vct_embed_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, i64, vp, vp, vp, i64, C.c_int, vp, u32, f32, vp]),
     "vct_sce_loss": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, f32, vp, vp, i64, vp, vp]),
     "vct_cast": (C.c_int, [C.c_int, C.c_int, vp, vp, i64, vp]),
     "vct_argmax_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp]),

@@ -87,95 +87,199 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int N, int S, int d, con
   }
 }
 
-// Deterministic scatter-add without float atomics.  Pass 1 (one thread per token position): integer
-// atomics build first_pos[id] = smallest position holding that id and cnt[id] = occurrences (both
-// order-independent).  Pass 2 (one workgroup per position): only the FIRST occurrence owns the
-// table row; a token seen once (the common case) is a straight row copy, a repeated token sums its
-// occurrences in increasing position order.  Bitwise reproducible; dtable is zero-filled first.
+// Deterministic scatter-add without float atomics.
+//   index pass   (one thread per token position): integer atomics build first_pos[id] = smallest position holding that id and
+//                cnt[id] = occurrences (both order-independent); only the FIRST occurrence owns the table row.
+//   sum pass     ONE launch with two roles.  Light: one WAVE per position; a token seen once (the common case) is a straight row
+//                copy, a token seen 2..8 times scans the later positions (1024 ids per trip, ballots) and adds its occurrences in
+//                increasing position order.  Heavy (the first 32 workgroups, 1024 threads): tokens seen more often, found by the
+//                workgroup itself in the count table: ordered compaction of the matches among 8192 positions per round, 16
+//                column-parallel slots over fixed subsequences of the ordered occurrence list, slot partials added in slot
+//                order.  ([CLS] sits in every caption: as a 256-thread workgroup among the 4 864 of the first version's
+//                one-workgroup-per-position kernel its chain of scan rounds and row fetches was the whole 44 us.)
+// Bitwise reproducible; the rows to write are zeroed by embed_prep_kernel first.
 __global__ void embed_index_kernel(int N, int S, const int64_t* __restrict__ ids, int64_t id_bstride, int64_t pad_id,
-                                   int32_t* __restrict__ first_pos, int32_t* __restrict__ cnt, int32_t* __restrict__ dirty) {
+                                   int32_t* __restrict__ first_pos, int32_t* __restrict__ cnt, int32_t* __restrict__ hdr,
+                                   int32_t* __restrict__ flat_cur) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n == 0) dirty[0] = 0;           // the prep kernel in front has consumed the list; the scatter behind refills it
+  if (n == 0) hdr[1] = N;                       // this call's positions: what the NEXT call's prep kernel zeroes
   if (n >= N) return;
   const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
+  flat_cur[n] = (int32_t)id;  // position-major copy: the passes behind scan it without an integer division per element
   if (id == pad_id) return;
   atomicMin(&first_pos[id], n);
   atomicAdd(&cnt[id], 1);
 }
 
+constexpr int EMB_LIGHT_MAX = 8;
+
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, const int64_t* __restrict__ ids,
-                                                        int64_t id_bstride, int64_t pad_id, const T* __restrict__ dx,
-                                                        float* __restrict__ dtable, const int32_t* __restrict__ first_pos,
-                                                        const int32_t* __restrict__ cnt, int32_t* __restrict__ dirty,
-                                                        const uint32_t* seed, uint32_t site, float p_drop) {
-  constexpr int VEC = EV<T>::VEC;
+__device__ __forceinline__ void embed_bwd_light(int n, int N, int d, const int32_t* __restrict__ flat, int32_t pad_id,
+                                                const T* __restrict__ dx, float* __restrict__ dtable,
+                                                const int32_t* __restrict__ first_pos, const int32_t* __restrict__ cnt,
+                                                const uint32_t* seed, uint32_t site, float p_drop) {
+  constexpr int VEC = EV<T>::VEC, MAXCH = 1024 / (64 * VEC) > 0 ? 1024 / (64 * VEC) : 1;      // d <= 1024: 2 (bf16) / 4 (fp32) chunks per lane
   using P = PackT<T, VEC>;
-  __shared__ int s_wcnt[16];
-  __shared__ int s_list[1024];
-  __shared__ float s_part[256 * VEC];                  // [slot][d] partial sums
-  const int n = blockIdx.x;
-  const int64_t id = ids[(size_t)(n / S) * id_bstride + (n % S)];
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int32_t id = flat[n];
   if (id == pad_id || first_pos[id] != n) return;       // not the owner of this table row
-  if (threadIdx.x == 0) dirty[1 + atomicAdd(&dirty[0], 1)] = (int32_t)id;   // rows this call writes (next call zeroes exactly these)
   const int occurrences = cnt[id];
+  if (occurrences > EMB_LIGHT_MAX) return;              // the heavy workgroups of this launch own it
   const Dropout dr = make_dropout(seed, site, p_drop);
-  // thread = (occurrence slot, 16-byte column chunk): a frequent token ([CLS] sits in every caption)
-  // is summed by `slots` threads per column in parallel, each over a fixed subsequence of the
-  // ordered occurrence list; the slot partials are then added in slot order -> deterministic
-  const int chunks = d / VEC, slots = 256 / chunks;
+  const int nch = d / (64 * VEC);                        // full chunks per lane (d is a multiple of 64 * VEC or smaller than it)
+  const int tailv = (d - nch * 64 * VEC) / VEC;          // lanes with one more vector (d % (64 * VEC) != 0)
+  float acc[MAXCH + 1][VEC];
+#pragma unroll
+  for (int c = 0; c <= MAXCH; c++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) acc[c][j] = 0.0f;
+  auto add_row = [&](int pos) {
+#pragma unroll
+    for (int c = 0; c <= MAXCH; c++) {
+      const bool on = c < nch || (c == nch && lane < tailv);
+      if (on) {
+        const int col = (c * 64 + lane) * VEC;
+        const P v = *reinterpret_cast<const P*>(dx + (size_t)pos * d + col);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) acc[c][j] += to_f<T>(v.v[j]) * drop_mult(dr, (uint32_t)pos * (uint32_t)d + (uint32_t)(col + j));
+      }
+    }
+  };
+  add_row(n);
+  int found = 1;
+  // 16 x 64 ids per trip, all loads independent: a token whose next occurrence is far away walks the id array in N / 1024
+  // dependent round trips (with 256 ids per trip the slowest wave of the kernel took 19 of them: 60 us)
+  constexpr int TRIP = 16;
+  for (int base = n + 1; base < N && found < occurrences; base += TRIP * 64) {
+    unsigned long long bal[TRIP];
+#pragma unroll
+    for (int u = 0; u < TRIP; u++) {
+      const int j = base + u * 64 + lane;
+      const bool mt = flat[min(j, N - 1)] == id && j < N;
+      bal[u] = __ballot(mt);
+    }
+#pragma unroll
+    for (int u = 0; u < TRIP; u++) {
+      unsigned long long mk = bal[u];
+      while (mk != 0ull) {                               // increasing position order
+        const int bit = __ffsll((long long)mk) - 1;
+        mk &= mk - 1ull;
+        add_row(base + u * 64 + bit);
+        found++;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c <= MAXCH; c++) {
+    const bool on = c < nch || (c == nch && lane < tailv);
+    if (on) {
+      const int col = (c * 64 + lane) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; j += 4)
+        *reinterpret_cast<float4*>(dtable + (size_t)id * d + col + j) = float4{acc[c][j], acc[c][j + 1], acc[c][j + 2], acc[c][j + 3]};
+    }
+  }
+}
+
+constexpr int EMB_HEAVY_WGS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void embed_bwd_kernel(int N, int d, int V, const int32_t* __restrict__ flat, int32_t pad_id,
+                                                         const T* __restrict__ dx, float* __restrict__ dtable,
+                                                         const int32_t* __restrict__ first_pos, const int32_t* __restrict__ cnt,
+                                                         const uint32_t* seed, uint32_t site, float p_drop) {
+  constexpr int VEC = EV<T>::VEC, NT = 1024, NWV = NT / 64, SUBS = 8;
+  using P = PackT<T, VEC>;
+  if (blockIdx.x >= EMB_HEAVY_WGS) {                    // light role: one wave per position
+    embed_bwd_light<T>((blockIdx.x - EMB_HEAVY_WGS) * NWV + (threadIdx.x >> 6), N, d, flat, pad_id, dx, dtable, first_pos, cnt, seed,
+                       site, p_drop);
+    return;
+  }
+  // heavy role (the FIRST workgroups of the grid, so the longest chains start first): workgroup h owns the tokens with more than
+  // EMB_LIGHT_MAX occurrences in its slices of the id range; it finds them itself (a list appended to by the light waves would need
+  // a second launch behind them: measured 17 us after the light pass instead of beside it)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_list = reinterpret_cast<int*>(smem);                          // [SUBS * NT] ordered matches of a round
+  int* s_wcnt = s_list + SUBS * NT;                                    // [SUBS * NWV]
+  int* s_off = s_wcnt + SUBS * NWV;                                    // [SUBS * NWV + 1] exclusive prefix (+ total), padded to 256
+  int* s_own = s_off + 256;                                            // [NT] owner positions found in a slice of NT positions
+  int* s_oid = s_own + NT;                                             // [NT] their ids
+  int* s_onum = s_oid + NT;                                            // [NT] their occurrence counts
+  int* s_ocnt = s_onum + NT;                                           // [NWV + 1], padded to 32
+  float* s_part = reinterpret_cast<float*>(s_ocnt + 32);               // [slots][d]
+  const Dropout dr = make_dropout(seed, site, p_drop);
+  const int chunks = d / VEC, slots = NT / chunks;                     // thread = (occurrence slot, 16-byte column chunk)
   const int chunk = threadIdx.x % chunks, slot = threadIdx.x / chunks;
   const bool active = slot < slots;
-  float acc[VEC];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int ibase = blockIdx.x * NT; ibase < V; ibase += EMB_HEAVY_WGS * NT) {
+   // this workgroup's heavy tokens among ids [ibase, ibase + NT): ONE coalesced look at the count table (walking the positions
+   // instead cost five dependent id -> table round trips), their owner positions compacted into s_own
+   {
+    const int pid = ibase + (int)threadIdx.x;
+    const int fp = first_pos[min(pid, V - 1)];
+    const int pc = cnt[min(pid, V - 1)];
+    const bool own = pid < V && pc > EMB_LIGHT_MAX;                     // the padding id is never counted
+    const unsigned long long ob = __ballot(own);
+    __syncthreads();                                    // the previous slice's readers of s_own are done
+    if (l == 0) s_ocnt[w] = __popcll(ob);
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; i++) off += s_ocnt[i];
+    if (own) {
+      const int slot_o = off + __popcll(ob & ((1ull << l) - 1ull));
+      s_own[slot_o] = fp; s_oid[slot_o] = pid; s_onum[slot_o] = pc;
+    }
+    if (threadIdx.x == NT - 1) s_ocnt[NWV] = off + __popcll(ob);
+    __syncthreads();
+   }
+   const int nown = s_ocnt[NWV];
+   for (int e = 0; e < nown; e++) {
+    const int n = s_own[e];
+    const int32_t id = s_oid[e];
+    const int occurrences = s_onum[e];
+    float acc[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; j++) acc[j] = 0.0f;
-  auto add_row = [&](int pos) {
-    const P v = *reinterpret_cast<const P*>(dx + (size_t)pos * d + chunk * VEC);
-#pragma unroll
-    for (int j = 0; j < VEC; j++)
-      acc[j] += to_f<T>(v.v[j]) * drop_mult(dr, (uint32_t)pos * (uint32_t)d + (uint32_t)(chunk * VEC + j));
-  };
-  if (occurrences == 1) {
-    if (active && slot == 0) add_row(n);
-  } else {
-    int seen = 0;                                       // occurrences consumed so far (global order index)
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    // ordered compaction of the matches among positions [base, base + SUBS * 256): the SUBS id loads of a thread are issued
-    // together, one ballot per wave and 256-position slice, ONE barrier, prefix over (slice, wave).  (SUBS = 20 -- the 4864
-    // positions of cfg-B in one round instead of five -- was measured and is SLOWER, 65 vs 44 us: the 20 KB position list is
-    // LDS of every one of the N workgroups, most of which copy a single row, and costs them their occupancy.)
-    constexpr int SUBS = 4;
-    for (int base = n; base < N && seen < occurrences; base += SUBS * 256) {
+    for (int j = 0; j < VEC; j++) acc[j] = 0.0f;
+    int seen = 0;                                        // occurrences consumed so far (global order index)
+    for (int base = n; base < N && seen < occurrences; base += SUBS * NT) {
+      // ordered compaction of the matches among positions [base, base + SUBS * NT): the SUBS id loads of a thread are issued
+      // together, one ballot per wave and NT-position slice, ONE barrier, prefix over (slice, wave)
       bool match[SUBS];
       unsigned long long bal[SUBS];
 #pragma unroll
       for (int sub = 0; sub < SUBS; sub++) {
-        const int j = min(base + sub * 256 + (int)threadIdx.x, N - 1);
-        match[sub] = ids[(size_t)(j / S) * id_bstride + (j % S)] == id;
+        match[sub] = flat[min(base + sub * NT + (int)threadIdx.x, N - 1)] == id;
       }
       __syncthreads();                                  // the previous round's readers of s_list / s_wcnt are done
 #pragma unroll
       for (int sub = 0; sub < SUBS; sub++) {
-        match[sub] = match[sub] && (base + sub * 256 + (int)threadIdx.x < N);
+        match[sub] = match[sub] && (base + sub * NT + (int)threadIdx.x < N);
         bal[sub] = __ballot(match[sub]);
-        if (l == 0) s_wcnt[sub * 4 + w] = __popcll(bal[sub]);
+        if (l == 0) s_wcnt[sub * NWV + w] = __popcll(bal[sub]);
       }
       __syncthreads();
-      int total = 0;
+      // exclusive prefix over the SUBS * NWV = 128 (slice, wave) counts by ONE wave (two entries per lane, shuffle scan); a serial
+      // walk over them by every thread cost the 16 waves ~20 us
+      if (w == 0) {
+        const int c0 = s_wcnt[2 * l], c1 = s_wcnt[2 * l + 1];
+        int incl = c0 + c1;
 #pragma unroll
-      for (int sub = 0; sub < SUBS; sub++) {
-#pragma unroll
-        for (int ww = 0; ww < 4; ww++) {
-          if (ww == w && match[sub]) s_list[total + __popcll(bal[sub] & ((1ull << l) - 1ull))] = base + sub * 256 + threadIdx.x;
-          total += s_wcnt[sub * 4 + ww];
-        }
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (l >= off) incl += t; }
+        const int excl = incl - (c0 + c1);
+        s_off[2 * l] = excl; s_off[2 * l + 1] = excl + c0;
+        if (l == 63) s_off[SUBS * NWV] = incl;
       }
       __syncthreads();
-      const int found = total;
+#pragma unroll
+      for (int sub = 0; sub < SUBS; sub++)
+        if (match[sub]) s_list[s_off[sub * NWV + w] + __popcll(bal[sub] & ((1ull << l) - 1ull))] = base + sub * NT + threadIdx.x;
+      const int found = s_off[SUBS * NWV];
+      __syncthreads();
       if (active) {
-        // slot s takes list entries whose GLOBAL order index is congruent to s (mod slots)
-        // Eight rows are fetched before the first one is added (the loads are independent, the ADDS keep their order):
-        // a token that occurs in every caption ([CLS]) is otherwise a chain of ~N/(1024/slots) dependent L2 round trips.
+        // slot s takes list entries whose GLOBAL order index is congruent to s (mod slots); eight rows are fetched before the
+        // first one is added (the loads are independent, the ADDS keep their order)
         constexpr int DEPTH = 8;
         for (int q = ((slot - seen) % slots + slots) % slots; q < found; q += DEPTH * slots) {
           P v[DEPTH];
@@ -198,17 +302,18 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int N, int S, int d, con
       }
       seen += found;
     }
-  }
-  __syncthreads();
-  if (active) {
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < VEC; j++) s_part[slot * d + chunk * VEC + j] = acc[j];
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float s = 0.0f;
-    for (int sl = 0; sl < slots; sl++) s += s_part[sl * d + c];
-    dtable[(size_t)id * d + c] = s;
+      for (int j = 0; j < VEC; j++) s_part[slot * d + chunk * VEC + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += NT) {
+      float sm = 0.0f;
+      for (int sl = 0; sl < slots; sl++) sm += s_part[sl * d + c];
+      dtable[(size_t)id * d + c] = sm;
+    }
+   }
   }
 }
 
@@ -506,11 +611,14 @@ extern "C" int vct_embed_fwd(int dtype, int B, int S, int d, const int64_t* ids,
 }
 
 // ONE launch in front of the scatter (it was three hipMemsetAsync calls = five fill kernels, 44 us): the occurrence tables
-// are reset and the dense gradient is zeroed -- all V rows, or (incremental) only the rows the PREVIOUS call wrote, whose ids
-// that call left in the dirty list: 4864 rows of 2 KB instead of 62.5 MB.
+// are reset and the dense gradient is zeroed -- all V rows, or (incremental) only the rows the PREVIOUS call wrote: the rows of the
+// ids of its batch, which that call left in its position-order id buffer (4864 rows of 2 KB instead of 62.5 MB; a row that occurs
+// k times is zeroed k times).  (A compacted list of the written rows, appended to by every owner wave, was measured first: 4 600
+// atomic increments of ONE counter serialise at ~11 ns each -- it took the scatter kernel from 44 to 65 us.)
 namespace vct {
 __global__ __launch_bounds__(256) void embed_prep_kernel(int V, int d, float* __restrict__ dtable, int32_t* __restrict__ first_pos,
-                                                         int32_t* __restrict__ cnt, int32_t* __restrict__ dirty, int incremental) {
+                                                         int32_t* __restrict__ cnt, const int32_t* __restrict__ flat_prev,
+                                                         const int32_t* __restrict__ hdr, int incremental) {
   const int gt = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
   for (int i = gt; i < V; i += nth) { first_pos[i] = 0x7f7f7f7f; cnt[i] = 0; }
   const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -519,10 +627,12 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(int V, int d, float* __
     const size_t n4 = (size_t)V * d / 4;
     for (size_t i = gt; i < n4; i += nth) dst[i] = z;
   } else {
-    const int nd = dirty[0], d4 = d / 4;
+    const int nprev = hdr[1], d4 = d / 4;
     const int w = gt >> 6, nw = nth >> 6, lane = threadIdx.x & 63;
-    for (int r = w; r < nd; r += nw) {                     // one wave per dirty row
-      float4* dst = reinterpret_cast<float4*>(dtable + (size_t)dirty[1 + r] * d);
+    for (int r = w; r < nprev; r += nw) {                  // one wave per position of the previous batch
+      const int id = flat_prev[r];
+      if (id < 0 || id >= V) continue;
+      float4* dst = reinterpret_cast<float4*>(dtable + (size_t)id * d);
       for (int c = lane; c < d4; c += 64) dst[c] = z;
     }
   }
@@ -530,28 +640,42 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(int V, int d, float* __
 }  // namespace vct
 
 extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_t* ids, int64_t id_batch_stride,
-                             int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int incremental, const uint32_t* seed,
-                             uint32_t site, float p_drop, void* stream) {
+                             int64_t pad_id, const void* dx, float* dtable, int32_t* id_ws, int64_t id_ws_ints, int incremental,
+                             const uint32_t* seed, uint32_t site, float p_drop, void* stream) {
   if (!dt_ok(dtype) || !ids || !dx || !dtable || !id_ws) return VCT_E_ARG;
   if (B <= 0 || S <= 0 || d <= 0 || V <= 0) return VCT_E_SHAPE;
-  if (d % vec_of(dtype) || d / vec_of(dtype) > 256 || (d % 4)) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
+  if (d % vec_of(dtype) || d / vec_of(dtype) > 256 || (d % 4) || d > 1024) return VCT_E_SHAPE;   // one 16-byte column chunk per thread
   if (((uintptr_t)dtable & 15)) return VCT_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int N = B * S;
   int32_t* first_pos = id_ws;
   int32_t* cnt = id_ws + V;
-  int32_t* dirty = id_ws + 2 * (size_t)V;                  // [0] = count, [1 ..] = ids of the rows written by the last call
-  vct::launch(embed_prep_kernel, dim3(incremental ? 512 : 2048), dim3(256), 0, st, V, d, dtable, first_pos, cnt, dirty,
+  // [first_pos V | count V | hdr 4 (hdr[1] = positions of the last call) | ids of the last call, position order]: the prep kernel
+  // runs FIRST and zeroes the rows of the ids the previous call left, then the index kernel overwrites them with this call's --
+  // the same buffer every call, so a recorded launch list replays correctly any number of times
+  int32_t* hdr = id_ws + 2 * (size_t)V;
+  int32_t* flat = hdr + 4;
+  if (id_ws_ints < 2 * (int64_t)V + 4 + N) return VCT_E_WORKSPACE;
+  vct::launch(embed_prep_kernel, dim3(incremental ? 512 : 2048), dim3(256), 0, st, V, d, dtable, first_pos, cnt, flat, hdr,
               incremental ? 1 : 0);
   VCT_CHECK_LAUNCH();
-  vct::launch(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt, dirty);
+  vct::launch(embed_index_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, S, ids, id_batch_stride, pad_id, first_pos, cnt, hdr, flat);
   VCT_CHECK_LAUNCH();
-  if (dtype == VCT_BF16)
-    vct::launch((embed_bwd_kernel<bf16_t>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const bf16_t*)dx, dtable, first_pos, cnt, dirty, seed, site, p_drop);
-  else
-    vct::launch((embed_bwd_kernel<float>), dim3(N), dim3(256), 0, st, N, S, d, ids, id_batch_stride, pad_id,
-                       (const float*)dx, dtable, first_pos, cnt, dirty, seed, site, p_drop);
+  const int vecb = vec_of(dtype);
+  const int slots = 1024 / (d / vecb);
+  const size_t heavy_lds = (size_t)(8 * 1024 + 8 * 16 + 256 + 3 * 1024 + 32) * sizeof(int) + (size_t)slots * d * sizeof(float);
+  const dim3 grid(EMB_HEAVY_WGS + (N + 15) / 16);
+  if (dtype == VCT_BF16) {
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VCT_E_SHAPE; attr = true; }
+    vct::launch((embed_bwd_kernel<bf16_t>), grid, dim3(1024), heavy_lds, st, N, d, V, flat, (int32_t)pad_id, (const bf16_t*)dx, dtable,
+                first_pos, cnt, seed, site, p_drop);
+  } else {
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute((const void*)embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VCT_E_SHAPE; attr = true; }
+    vct::launch((embed_bwd_kernel<float>), grid, dim3(1024), heavy_lds, st, N, d, V, flat, (int32_t)pad_id, (const float*)dx, dtable,
+                first_pos, cnt, seed, site, p_drop);
+  }
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -293,6 +293,7 @@ def embed_fwd(ids, S, table, pos, x, dropout: Drop = None):
 
 
 _embed_ws = {}
+_embed_ws_retired = []
 
 
 def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, exclusive: bool = False):
@@ -307,15 +308,20 @@ def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, excl
     if id_ws is None:
         key = (V, dx.device)
         ent = _embed_ws.get(key)
-        if ent is None:      # [first_pos V | count V | dirty count 1 | dirty ids <= V]: never has to grow (recordings bake its address)
-            ent = _embed_ws[key] = [torch.zeros(3 * V + 1, dtype=torch.int32, device=dx.device), None]
+        need = 2 * V + 4 + max(B * S, 65536)
+        if ent is None or ent[0].numel() < need:
+            # [first_pos V | count V | header 4 (positions of the last call) | ids in position order N]; room
+            # for 65536 positions up front (recordings bake its address); an outgrown one stays alive for the recordings that use it
+            if ent is not None:
+                _embed_ws_retired.append(ent[0])
+            ent = _embed_ws[key] = [torch.zeros(need, dtype=torch.int32, device=dx.device), None]
         id_ws = ent[0]
         incremental = exclusive and ent[1] == dtable.data_ptr()
         ent[1] = dtable.data_ptr() if exclusive else None
     else:
-        assert id_ws.numel() >= 3 * V + 1
+        assert id_ws.numel() >= 2 * V + 4 + B * S
     L.check(L.load().vct_embed_bwd(L.dtype_code(dx.dtype), B, S, dx.shape[1], V, ids.data_ptr(),
-                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), id_ws.data_ptr(), int(incremental),
+                                   ids.stride(0), int(pad_id), dx.data_ptr(), dtable.data_ptr(), id_ws.data_ptr(), id_ws.numel(), int(incremental),
                                    s, site, p, L.stream_ptr()), "vct_embed_bwd")
 
 
