@@ -25,7 +25,7 @@ struct alignas(16) PV8 { bf16_t e[8]; };
 
 // EPI = false: bias only, the row slab holds bf16 (one LDS pass per 128 rows); EPI = true: the slab holds fp32 and the store
 // phase applies the full epilogue on 8 consecutive columns per thread.
-template <int TA, int TB, int TM, int TN, bool EPI>
+template <int TA, int TB, int TM, int TN, bool EPI, int NSTG>
 __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0), KSPLIT = A_MC && B_MC;
   constexpr int NW = 8, NT = 512;
@@ -93,50 +93,78 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
   const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
   const bf16_t* dact = reinterpret_cast<const bf16_t*>(p.dact);
 
-  int w = w_begin + slot;
-  int m0 = 0, n0 = 0;
-  if (w < w_end) { item(w, m0, n0); issue(m0, n0, 0, 0); }
+  // The flat list of (tile, K stage) steps of this workgroup.  NSTG LDS stages: step s computes from stage s % NSTG while the DMA
+  // of step s + NSTG - 1 is issued, so a load has NSTG - 1 steps of MFMA time to land (NSTG = 2: one step; NSTG = 3: two steps,
+  // waits are `vmcnt(pieces of the step in between)` instead of `vmcnt(0)`).  Measured (tools/gemm_pt_bench.py,
+  // VCT_GEMM_PT_STAGES=3): the deeper prefetch buys nothing -- 128 x 128 tiles (96 KB: one workgroup per CU instead of two)
+  // decoder QKV 14.2 -> 17.3 us, FFN1 19.6 -> 24.2, batch-1024 FFN1 66 -> 79; 64 x 128 tiles (72 KB, still two per CU) 22.0 ->
+  // 21.9 / 84 -> 87 -- so the K loop is not waiting for its operands (the CU's L2 -> LDS stream runs at 12-16 B/clk of the 54
+  // it can reach because the loop asks for no more); two stages stay the default.
+  struct Cur { int w, m0, n0, kt; bool valid; };
+  auto advance = [&](Cur& c) {
+    if (c.kt + 1 < nkt) { c.kt++; return; }
+    c.kt = 0; c.w += nxw;
+    if (c.w < w_end) item(c.w, c.m0, c.n0); else c.valid = false;
+  };
+  Cur c;
+  c.w = w_begin + slot; c.m0 = 0; c.n0 = 0; c.kt = 0; c.valid = c.w < w_end;
+  if (!c.valid) return;
+  item(c.w, c.m0, c.n0);
+  Cur pf = c;                                             // the step whose stage is issued next
+  int pend_next = 0;                                      // DMA instructions of this wave in flight for the step AFTER the current one
+#pragma unroll
+  for (int i = 0; i < NSTG - 1; i++) {
+    if (pf.valid) {
+      issue(pf.m0, pf.n0, pf.kt, i);
+      if (i == 1) pend_next = pf.kt < kt_full ? NP : 0;
+    }
+    advance(pf);
+  }
   int buf = 0;
-  for (; w < w_end; w += nxw) {
-    int m1 = 0, n1 = 0;
-    const bool have_next = w + nxw < w_end;
-    if (have_next) item(w + nxw, m1, n1);
-    for (int kt = 0; kt < nkt; kt++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the current stage has landed
-      __builtin_amdgcn_s_barrier();                          // ... everyone's has; everyone is done with the other buffer
-      asm volatile("" ::: "memory");
-      // the next stage (this tile's, or the first stage of the NEXT tile, which then flies under this tile's epilogue): a full stage
-      // goes by DMA, one instruction after each row tile's MFMAs; a ragged one takes the register path up front
-      const bool nx_own = kt + 1 < nkt;
-      const int nx_m = nx_own ? m0 : m1, nx_n = nx_own ? n0 : n1, nx_kt = nx_own ? kt + 1 : 0;
-      const bool nx_any = nx_own || have_next;
-      const bool nx_dma = nx_any && nx_kt < kt_full;
-      if (nx_any && !nx_dma) issue(nx_m, nx_n, nx_kt, buf ^ 1);
-      unsigned char* nb = lds + (buf ^ 1) * STAGE;
-      const unsigned char* la = lds + buf * STAGE;
-      const unsigned char* lb = la + BM * 128;
+  bool fresh = true;                                      // first step, or the step after an epilogue (its global stores / loads count too)
+  while (c.valid) {
+    const int m0 = c.m0, n0 = c.n0;
+    if (NSTG > 2 && !fresh && pend_next == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the current stage has landed
+    __builtin_amdgcn_s_barrier();                          // ... everyone's has; everyone is done with the stage issued into next
+    asm volatile("" ::: "memory");
+    fresh = false;
+    // the stage NSTG - 1 steps ahead (this tile's, or one of the first stages of the NEXT tile, which then fly under this tile's
+    // epilogue): a full stage goes by DMA, one instruction after each row tile's MFMAs; a ragged one takes the register path up front
+    const int tb = (buf + NSTG - 1) % NSTG;
+    const bool nx_any = pf.valid;
+    const bool nx_dma = nx_any && pf.kt < kt_full;
+    const int nx_m = pf.m0, nx_n = pf.n0, nx_kt = pf.kt;
+    if (nx_any && !nx_dma) issue(nx_m, nx_n, nx_kt, tb);
+    unsigned char* nb = lds + tb * STAGE;
+    const unsigned char* la = lds + buf * STAGE;
+    const unsigned char* lb = la + BM * 128;
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        bf16x8 fa[TM], fb[TN];
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = frag2<A_MC, BM, KSPLIT>(la, wm * WM + i * 16, ks, lane);
+      for (int i = 0; i < TM; i++) fa[i] = frag2<A_MC, BM, KSPLIT>(la, wm * WM + i * 16, ks, lane);
 #pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = frag2<B_MC, BN, KSPLIT>(lb, wn * WNC + j * 16, ks, lane);
+      for (int j = 0; j < TN; j++) fb[j] = frag2<B_MC, BN, KSPLIT>(lb, wn * WNC + j * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
+      for (int i = 0; i < TM; i++) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-          const int q = ks * TM + i;                         // DMA issue slot
-          if (q < NP && nx_dma) {
-            if (q < BM / 64) dma_piece<A_MC, BM, NW>(nb, A, p.lda, nx_m, p.M, nx_kt * BK2, wave, lane, q);
-            else dma_piece<B_MC, BN, NW>(nb + BM * 128, B, p.ldb, nx_n, p.N, nx_kt * BK2, wave, lane, q - BM / 64);
-          }
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        const int q = ks * TM + i;                         // DMA issue slot
+        if (q < NP && nx_dma) {
+          if (q < BM / 64) dma_piece<A_MC, BM, NW>(nb, A, p.lda, nx_m, p.M, nx_kt * BK2, wave, lane, q);
+          else dma_piece<B_MC, BN, NW>(nb + BM * 128, B, p.ldb, nx_n, p.N, nx_kt * BK2, wave, lane, q - BM / 64);
         }
       }
-      buf ^= 1;
     }
-    // ---- epilogue: the stage just consumed (buf ^ 1 after the flip) is free until the next step issues into it ----
-    unsigned char* slab = lds + (buf ^ 1) * STAGE;
+    if (NSTG > 2) pend_next = nx_dma ? NP : 0;             // with three stages the stage issued here is the one after next
+    const bool tile_done = c.kt == nkt - 1;
+    unsigned char* slab = lds + buf * STAGE;               // the stage just consumed is free until the next step issues into ...
+    advance(c); advance(pf);
+    buf = (buf + 1) % NSTG;
+    if (!tile_done) continue;
+    // ---- epilogue ----
+    fresh = true;
     float bj[TN][4];
     if constexpr (!EPI) {
 #pragma unroll
@@ -234,28 +262,32 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
-    m0 = m1; n0 = n1;
     // the next step's barrier (after its vmcnt wait) orders the last slab reads before the DMA that reuses this stage
   }
 }
 
-template <int TA, int TB, int TM, int TN, bool EPI> static int gpt_launch(const GemmP& p, hipStream_t st) {
-  constexpr int LDSB = 2 * (32 * TM + 64 * TN) * 128;
+template <int TA, int TB, int TM, int TN, bool EPI, int NSTG> static int gpt_launch(const GemmP& p, hipStream_t st) {
+  constexpr int LDSB = NSTG * (32 * TM + 64 * TN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   constexpr int per_cu = LDSB <= 80 * 1024 ? 2 : 1;
-  vct::launch(gemm_pt_kernel<TA, TB, TM, TN, EPI>, dim3(per_cu * persistent_grid(st)), dim3(512), (size_t)LDSB, st, p);
+  vct::launch(gemm_pt_kernel<TA, TB, TM, TN, EPI, NSTG>, dim3(per_cu * persistent_grid(st)), dim3(512), (size_t)LDSB, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
 
+template <int TA, int TB, int NSTG> static int gpt_dispatch_s(const GemmP& p, int tile, bool epi, hipStream_t st) {
+  if (tile == 0) return epi ? gpt_launch<TA, TB, 4, 2, true, NSTG>(p, st) : gpt_launch<TA, TB, 4, 2, false, NSTG>(p, st);     // 128 x 128
+  return epi ? gpt_launch<TA, TB, 2, 2, true, NSTG>(p, st) : gpt_launch<TA, TB, 2, 2, false, NSTG>(p, st);                    // 64 x 128
+}
 template <int TA, int TB> static int gpt_dispatch(const GemmP& p, int tile, bool epi, hipStream_t st) {
-  if (tile == 0) return epi ? gpt_launch<TA, TB, 4, 2, true>(p, st) : gpt_launch<TA, TB, 4, 2, false>(p, st);     // 128 x 128
-  return epi ? gpt_launch<TA, TB, 2, 2, true>(p, st) : gpt_launch<TA, TB, 2, 2, false>(p, st);                    // 64 x 128
+  static const char* senv = getenv("VCT_GEMM_PT_STAGES");
+  const int stages = senv != nullptr ? atoi(senv) : 2;
+  return stages == 3 ? gpt_dispatch_s<TA, TB, 3>(p, tile, epi, st) : gpt_dispatch_s<TA, TB, 2>(p, tile, epi, st);
 }
 
 // Eligibility + launch (called from vct_gemm after the skinny and the vocabulary kernels).  VCT_GEMM_PT: bit 0 = NT products,
