@@ -326,11 +326,22 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   const long tiles = (long)p.tiles_m * p.tiles_n;
   p.zmajor = 0;
   if (form == 1 && (mask & 8) && d->out_dtype == VCT_BF16 && !d->bias && !d->bias_grad && d->split_k != 1 && d->workspace != nullptr &&
-      tiles <= 128 && nkt >= 128 && d->M >= 2048) {
+      tiles <= 512 && nkt >= 128 && d->M >= 2048) {
     // NT with a vocabulary-long K and a narrow output (dX = dlogits W_g through the transposed weight shadow): split over K so that
     // every CU gets one item, fp32 partials + reduce.  K split outermost, N fastest inside: the tiles that read the same rows of
     // the 297 MB A operand sit on neighbouring CUs of one XCD and pull them from HBM once.
-    int split = d->split_k > 1 ? d->split_k : (int)(256 / tiles);
+    // the split that minimises (rounds of items over the CUs) x (K stages per item) among those whose partials fit the workspace:
+    // 38 tiles (cfg-B) -> 6 (228 items, one round of 80 stages); 152 tiles (batch 1024) -> 5 (760 items, three rounds of 96)
+    int split = d->split_k > 1 ? d->split_k : 0;
+    if (split == 0) {
+      const long ncu = persistent_grid(st);
+      long best = -1;
+      for (int sp = 2; sp <= 16; sp++) {
+        if ((int64_t)sp * d->M * d->N * 4 > d->workspace_bytes) break;
+        const long per = (nkt + sp - 1) / sp, cost = ((tiles * sp + ncu - 1) / ncu) * per;
+        if (best < 0 || cost < best) { best = cost; split = sp; }
+      }
+    }
     if (split >= 2) {
       p.kt_per_split = (nkt + split - 1) / split;
       p.split = (nkt + p.kt_per_split - 1) / p.kt_per_split;

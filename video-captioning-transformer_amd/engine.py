@@ -706,7 +706,9 @@ class DecoderEngine(_StackBase):
         dl, y = b.t["dlogits_used"], b.t["nf.y"]
         dy = b.get("dy", (M, d), self.dt)
         if getattr(self, "_wgt", None) is not None:
-            ops.gemm(dl, self._wgt, dy, ta=False, tb=True, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
+            # fp32 partials of the split over the vocabulary-long K: room for the 6-way split of cfg-B / the 5-way one at batch 1024
+            ws = b.get("gen_dx_ws", (6 * dy.shape[0] * dy.shape[1],), torch.float32)
+            ops.gemm(dl, self._wgt, dy, ta=False, tb=True, k_valid=self.V, workspace=ws, tag="gen_dx")
         else:
             ops.gemm(dl, self.W("generator.weight"), dy, ta=False, tb=False, k_valid=self.V, workspace=self.gemm_ws(), tag="gen_dx")
         # the vocabulary weight gradient: with a gradient exchange it goes out first (its bucket is a third of the bytes and
