@@ -243,15 +243,21 @@ def main():
             from vct_amd.trainer import ShardedExchange
             coll, why = None, None
             if os.environ.get("VCT_DIST_BACKEND", "nccl") == "nccl":
+                good = 0
                 try:
                     coll = RcclColl(device=device)
-                    ok = torch.tensor([1 if coll.self_test() else 0], device=device)
-                    if dist.is_initialized():
-                        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                    if int(ok) != 1:
-                        coll, why = None, "self-test of the collectives failed"
+                    good = 1 if coll.self_test() else 0
+                    if not good:
+                        why = "self-test of the collectives failed"
                 except Exception as e:      # never silently: say why the library's communicator is not carrying the gradients
                     coll, why = None, repr(e)
+                # ONE decision for the whole job: a rank that fell back alone would wait in torch.distributed collectives the
+                # others never enter
+                ok = torch.tensor([good], device=device)
+                if dist.is_initialized():
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok) != 1:
+                    coll, why = None, why or "vct_comm failed on another rank"
             else:
                 why = "VCT_DIST_BACKEND is not nccl"
             if coll is None:
@@ -311,6 +317,7 @@ def main():
         loss = trainer.step(feats, mask, ids)
     sync()
     elapsed = time.perf_counter() - t0
+    final_loss = float(loss)          # of the last TIMED step (the loss buffer is static: the untimed passes below overwrite it)
     taps = {tag: ops.tap_collect(tag) for tag in ops.TAPS}
     # second pass, untimed: every bracket, fresh recordings (a recording contains the brackets that were active when it was made)
     ops.taps_enable(True)
@@ -348,7 +355,6 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
-    final_loss = float(loss)
 
     if rank == 0:
         fl = algorithmic_flops(args.batch)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 5
+#define VCT_ABI_VERSION 6
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -390,7 +390,7 @@ int vct_decode_ln2(int M, int K, const float* x, int64_t ldx, const float* g1, c
  *                                  the new token), PARTIAL out-projection per head: part_out[h][d]
  *   kind 1  cross-attention block  x1 -> q, attention over the memory's Lk cached K/V rows, partial out-projection per head
  *   kind 2  feed-forward block     x2 -> act(W1 x2 + b1) per 64 hidden units, partial linear2 per unit group: part_out[ff/64][d]
- *   kind 3  generator              y -> logits fp32 [V] (part_out)
+ *   kind 3  generator              y -> logits fp32 [V] (part_out) (+ the greedy selection of the token, see sel_ws)
  * The input vector of every launch is built by each workgroup: the embedded token (id / table / pos_row) or
  * res + res_bias + sum_c part[c] (the previous block's residual, the bias of its second product, its partial vectors),
  * followed by LayerNorm(g1, b1) and LayerNorm(g2, b2) when given; x_out receives it (the next block's residual).
@@ -411,6 +411,11 @@ typedef struct vct_decode_block_desc {
   const void* kc; const void* vc; int64_t kv_ld;
   const void* w_b; int64_t ld_b;
   float* part_out;
+  /* kind 3 only, optional (sel_ws != NULL): the greedy selection of vct_greedy_select for this ONE caption inside the generator
+   * launch -- every workgroup leaves its (max, first index) pair in sel_ws (fp32 [2 * ceil(V / 128) + 1], zero-initialised once:
+   * the last word is a ticket counter the launch leaves at zero), the last one to finish writes tok_out[0] and the end-of-sequence
+   * bookkeeping (ended[0], ended_count, all_ended_at = min(., t)). */
+  float* sel_ws; int64_t* tok_out; int64_t end_id; uint8_t* ended; int32_t* ended_count; int64_t* all_ended_at; int32_t t, pad1;
 } vct_decode_block_desc;
 int vct_decode_block_supported(int dtype, int d, int H, int ff, int Lk);
 int vct_decode_block(const vct_decode_block_desc* d, void* stream);

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -71,7 +71,8 @@ class DecodeBlockDesc(C.Structure):
     _fields_ = [("kind", i32), ("d", i32), ("ff", i32), ("V", i32), ("Lk", i32), ("act", i32),
                 ("id", vp), ("table", vp), ("pos_row", vp), ("res", vp), ("res_bias", vp), ("part", vp), ("n_part", i32), ("pad0", i32),
                 ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("x_out", vp), ("w_a", vp), ("ld_a", i64), ("b_a", vp), ("slot", vp),
-                ("kc", vp), ("vc", vp), ("kv_ld", i64), ("w_b", vp), ("ld_b", i64), ("part_out", vp)]
+                ("kc", vp), ("vc", vp), ("kv_ld", i64), ("w_b", vp), ("ld_b", i64), ("part_out", vp),
+                ("sel_ws", vp), ("tok_out", vp), ("end_id", i64), ("ended", vp), ("ended_count", vp), ("all_ended_at", vp), ("t", i32), ("pad1", i32)]
 
 
 DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}

@@ -47,6 +47,9 @@ struct DbP {
   float* part_out;                                                 // [gridDim.x][d]
   // generator
   const bf16_t* wg; long ldg; const float* bg; float* logits; int V;
+  // ... + greedy selection by the last workgroup to finish (sel_ws != nullptr)
+  float* sel_ws;                  // [2 * gridDim.x] (value, index) per workgroup, then ONE int ticket counter (left zero)
+  int64_t* tok_out; long long end_id; uint8_t* ended; int32_t* ended_count; unsigned long long* all_ended_at; int t;
 };
 
 __device__ __forceinline__ void unpack8(const uint4 v, float (&o)[8]) {
@@ -362,12 +365,72 @@ __global__ __launch_bounds__(DB_THREADS) void decode_gen_kernel(const DbP p) {
     for (int u = 0; u < 8; u++) xr[c][u] = xs[c * 512 + lane * 8 + u];
   float out[NR];
   rows_dot<NR, NCH>(w, xr, out);
-  if (lane < NR) {
-    float mine = 0.0f;
+  float mine = 0.0f;
 #pragma unroll
-    for (int r = 0; r < NR; r++) mine = lane == r ? out[r] : mine;
-    const int n = base + lane;
-    if (n < p.V) p.logits[n] = mine + bias_r;
+  for (int r = 0; r < NR; r++) mine = lane == r ? out[r] : mine;
+  mine += bias_r;
+  const int n = base + lane;
+  const bool have = lane < NR && n < p.V;
+  if (have) p.logits[n] = mine;
+  if (p.sel_ws == nullptr) return;
+  // ---- greedy selection (MMT4Caption.py:166-171; torch.max: the FIRST maximal index): workgroup arg-max -> (value, index) pair
+  // written through the L2 -> ticket; the last workgroup reduces the pairs.  The separate arg-max launch over the 122 KB of
+  // logits cost 6.7 us per token.  Same comparison as argmax_rows_kernel: larger value, then smaller index.
+  float bv = have ? mine : -INFINITY;
+  int bi = have ? n : 0x7fffffff;
+  auto better = [](float v, int i, float bv_, int bi_) { return v > bv_ || (v == bv_ && i < bi_); };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  __shared__ float s_v[DB_WAVES];
+  __shared__ int s_i[DB_WAVES];
+  __shared__ int s_last;
+  if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+  __syncthreads();
+  int* ticket = reinterpret_cast<int*>(p.sel_ws + 2 * gridDim.x);
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 1; w < DB_WAVES; w++) if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 pr = {bv, __int_as_float(bi)};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.sel_ws + 2 * blockIdx.x), __builtin_bit_cast(unsigned long long, pr),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through store has completed (cf. the split-K reduce of vct_gemm_bf16_kernel.h)
+    s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  bv = -INFINITY; bi = 0x7fffffff;
+  for (int g = tid; g < (int)gridDim.x; g += DB_THREADS) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.sel_ws + 2 * g), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    const f32x2 pr = __builtin_bit_cast(f32x2, u);
+    const int gi = __float_as_int(pr[1]);
+    if (better(pr[0], gi, bv, bi)) { bv = pr[0]; bi = gi; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  __syncthreads();                                       // s_v / s_i of the first reduction have been read
+  if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 1; w < DB_WAVES; w++) if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+    const int tok = (bi == 0x7fffffff) ? 0 : bi;
+    p.tok_out[0] = tok;
+    if (p.ended != nullptr && tok == p.end_id && !p.ended[0]) {      // one caption: it completes the set by itself
+      p.ended[0] = 1;
+      if (atomicAdd(p.ended_count, 1) + 1 == 1) atomicMin(p.all_ended_at, (unsigned long long)p.t);
+    }
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next token
   }
 }
 
@@ -401,6 +464,10 @@ extern "C" int vct_decode_block(const vct_decode_block_desc* q, void* stream) {
   p.w1 = p.w_in; p.ld1 = p.ld_in; p.b1f = p.b_in; p.w2 = p.w_o; p.ld2 = p.ld_o; p.act = q->act;
   p.part_out = q->part_out;
   p.wg = p.w_in; p.ldg = p.ld_in; p.bg = p.b_in; p.logits = q->part_out; p.V = q->V;
+  p.sel_ws = q->kind == 3 ? q->sel_ws : nullptr;
+  p.tok_out = q->tok_out; p.end_id = q->end_id; p.ended = q->ended; p.ended_count = q->ended_count;
+  p.all_ended_at = reinterpret_cast<unsigned long long*>(q->all_ended_at); p.t = q->t;
+  if (p.sel_ws != nullptr && (!p.tok_out || !p.ended || !p.ended_count || !p.all_ended_at || q->t < 0)) return VCT_E_ARG;
   if (!q->w_a || !q->b_a || !q->part_out || (q->ld_a % 8) || ((uintptr_t)q->w_a & 15)) return VCT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (q->kind == 0 || q->kind == 1) {

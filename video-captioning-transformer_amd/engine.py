@@ -931,9 +931,9 @@ def _decoder_block_decode_ok(self, st: DecodeState) -> bool:
 
 
 def _decoder_decode_step_block(self, st: DecodeState, t: int, end_id: int):
-    """The step of _decoder_decode_step for ONE caption in 3 launches per layer + 2: self-attention block, cross-attention block,
+    """The step of _decoder_decode_step for ONE caption in 3 launches per layer + 1: self-attention block, cross-attention block,
     feed-forward block (each: first product + attention / activation + the second product split over the workgroups that own the
-    first, as partial vectors), generator, arg-max.  The partial vectors, the residual, the second product's bias and the
+    first, as partial vectors), generator (its last workgroup also selects the token).  The partial vectors, the residual, the second product's bias and the
     LayerNorm(s) are folded by the prologue of the next launch (csrc/vct_decode_block.hip)."""
     d, H, L, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.Te, st.Lmax, self.cfg["ff"]
     b = st.b
@@ -962,11 +962,15 @@ def _decoder_decode_step_block(self, st: DecodeState, t: int, end_id: int):
                          ff=ff, act=self.cfg["activation"], part_out=f_part)
         prev = (self.F(lp + "linear2.bias"), (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias")))
     logits = b.get("klogits", (1, self.Vp), f32)
+    sel = b.t.get("ksel")
+    if sel is None or sel.numel() < 2 * ((self.V + 127) // 128) + 1:
+        sel = b.get("ksel", (2 * ((self.V + 127) // 128) + 1,), f32)
+        sel.zero_()                               # the ticket counter: every launch leaves it at zero again
     ops.decode_block("gen", d, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1],
                      ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), w_a=self.W("generator.weight"),
-                     b_a=self.F("generator.bias"), V=self.V, part_out=logits)
+                     b_a=self.F("generator.bias"), V=self.V, part_out=logits,
+                     select=(sel, st.ys[0, t:t + 1], end_id, st.ended, st.ended_count, st.all_ended_at, t))
     st.last_logits = logits
-    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
 def _decoder_fused_decode_ok(self, st: DecodeState) -> bool:

@@ -416,7 +416,7 @@ def decode_gemv(W, out, B, *, bias=None, pro="none", x_in=None, ln1=None, ln2=No
 
 
 def decode_block(kind: str, d: int, *, w_a, b_a, part_out, embed=None, res=None, res_bias=None, part=None, ln1=None, ln2=None, x_out=None,
-                 slot=None, kc=None, vc=None, kv_ld=0, Lk=1, w_b=None, ff=0, act=None, V=0):
+                 slot=None, kc=None, vc=None, kv_ld=0, Lk=1, w_b=None, ff=0, act=None, V=0, select=None):
     """One block of the batch-1 greedy-decode step (include/vct_hip.h, vct_decode_block): kind in {'self', 'cross', 'ffn', 'gen'}.
     embed = (id view [1] int64, table fp32 [V, d], pos_row fp32 [d]) or the vector res + res_bias + sum(part) (fp32 [d] / [n, d])."""
     q = L.DecodeBlockDesc()
@@ -437,6 +437,11 @@ def decode_block(kind: str, d: int, *, w_a, b_a, part_out, embed=None, res=None,
     if w_b is not None:
         q.w_b, q.ld_b = w_b.data_ptr(), _ld(w_b)
     q.part_out = part_out.data_ptr()
+    if select is not None:      # kind 'gen': (sel_ws fp32 [2 * ceil(V / 128) + 1] zeroed, out id view [1], end_id, ended, ended_count, all_ended_at, t)
+        ws, out, end_id, ended, ended_count, all_ended_at, t = select
+        assert ws.numel() >= 2 * ((V + 127) // 128) + 1
+        q.sel_ws, q.tok_out, q.end_id, q.ended = ws.data_ptr(), out.data_ptr(), int(end_id), ended.data_ptr()
+        q.ended_count, q.all_ended_at, q.t = ended_count.data_ptr(), all_ended_at.data_ptr(), int(t)
     L.check(L.load().vct_decode_block(q, L.stream_ptr()), "vct_decode_block")
 
 
