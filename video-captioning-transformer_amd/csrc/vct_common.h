@@ -54,11 +54,39 @@ __device__ __forceinline__ float dact_f(int act, float x) {
 __device__ __forceinline__ void erf_cdf_pdf_fast(float x, float& cdf, float& pdf) {
   const float ax = fabsf(x) * 0.70710678118654752f;
   const float e = __expf(-ax * ax);                                   // = exp(-x^2 / 2)
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);     // v_rcp_f32 (1 ulp); __frcp_rn expands to a ten-instruction correctly rounded division
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * e;                              // erf(|x| / sqrt2)
   cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
   pdf = 0.3989422804014327f * e;
+}
+// The same for TWO elements per lane: the polynomial, the scalings and the sign transfer go through packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue slot), only exp and rcp stay per element.  The epilogues of the FFN
+// GEMMs spend their time in exactly this arithmetic (tools/ffn1_epi_bench.py: linear1 forward 19 us with a bias-only epilogue,
+// 29 us with GELU).
+typedef __attribute__((ext_vector_type(2))) float vf2;
+__device__ __forceinline__ void erf_cdf_pdf_fast2(const vf2 x, vf2& cdf, vf2& pdf) {
+  const vf2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const vf2 m = -ax * ax;
+  vf2 e; e[0] = __expf(m[0]); e[1] = __expf(m[1]);
+  const vf2 den = ax * 0.3275911f + 1.0f;
+  vf2 t; t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+  const vf2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const vf2 erf_abs = 1.0f - poly * e;
+  vf2 sg; sg[0] = copysignf(erf_abs[0], x[0]); sg[1] = copysignf(erf_abs[1], x[1]);
+  cdf = sg * 0.5f + 0.5f;
+  pdf = e * 0.3989422804014327f;
+}
+__device__ __forceinline__ vf2 act_fast_f2(int act, const vf2 x) {
+  if (act == VCT_ACT_GELU) { vf2 c, d; erf_cdf_pdf_fast2(x, c, d); return x * c; }
+  if (act == VCT_ACT_RELU) { vf2 r; r[0] = fmaxf(x[0], 0.0f); r[1] = fmaxf(x[1], 0.0f); return r; }
+  return x;
+}
+__device__ __forceinline__ vf2 dact_fast_f2(int act, const vf2 x) {
+  if (act == VCT_ACT_GELU) { vf2 c, d; erf_cdf_pdf_fast2(x, c, d); return c + x * d; }
+  vf2 r = {1.0f, 1.0f};
+  if (act == VCT_ACT_RELU) { r[0] = x[0] > 0.0f ? 1.0f : 0.0f; r[1] = x[1] > 0.0f ? 1.0f : 0.0f; }
+  return r;
 }
 __device__ __forceinline__ float act_fast_f(int act, float x) {
   if (act == VCT_ACT_GELU) { float c, d; erf_cdf_pdf_fast(x, c, d); return x * c; }

@@ -429,14 +429,15 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       if (has_d) dv = *reinterpret_cast<const OutV*>(dact + (size_t)row * p.ld_dact + col);
       if (has_a) av = *reinterpret_cast<const OutV*>(addend + (size_t)row * p.ld_addend + col);
 #pragma unroll
-      for (int q = 0; q < VO; q++) {
-        float x = v[q] + bv[q];
-        pv.e[q] = from_f<TO>(x);
-        x = act_fast_f(p.act, x);
-        if (has_d) x *= dact_fast_f(p.dact_kind, to_f<TO>(dv.e[q]));
-        x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q));
-        if (has_a) x += to_f<TO>(av.e[q]);
-        ov.e[q] = from_f<TO>(x);
+      for (int q = 0; q < VO; q += 2) {                      // pairs: packed fp32 arithmetic in the activation (vct_common.h)
+        vf2 x = {v[q] + bv[q], v[q + 1] + bv[q + 1]};
+        pv.e[q] = from_f<TO>(x[0]); pv.e[q + 1] = from_f<TO>(x[1]);
+        x = act_fast_f2(p.act, x);
+        if (has_d) x *= dact_fast_f2(p.dact_kind, vf2{to_f<TO>(dv.e[q]), to_f<TO>(dv.e[q + 1])});
+        const uint32_t di = (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q);
+        x *= vf2{drop_mult(dr, di), drop_mult(dr, di + 1u)};
+        if (has_a) x += vf2{to_f<TO>(av.e[q]), to_f<TO>(av.e[q + 1])};
+        ov.e[q] = from_f<TO>(x[0]); ov.e[q + 1] = from_f<TO>(x[1]);
       }
       if (nt_store) {
         // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident

@@ -231,14 +231,15 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
               if (has_d) dv = *reinterpret_cast<const PV8*>(dact + (size_t)row * p.ld_dact + col);
               if (has_a) av = *reinterpret_cast<const PV8*>(addend + (size_t)row * p.ld_addend + col);
 #pragma unroll
-              for (int qq = 0; qq < 8; qq++) {
-                float x = v[qq] + bv[qq];
-                pv.e[qq] = f2bf(x);
-                x = act_fast_f(p.act, x);
-                if (has_d) x *= dact_fast_f(p.dact_kind, bf2f(dv.e[qq]));
-                x *= drop_mult(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + qq));
-                if (has_a) x += bf2f(av.e[qq]);
-                ov.e[qq] = f2bf(x);
+              for (int qq = 0; qq < 8; qq += 2) {            // pairs: packed fp32 arithmetic in the activation (vct_common.h)
+                vf2 x = {v[qq] + bv[qq], v[qq + 1] + bv[qq + 1]};
+                pv.e[qq] = f2bf(x[0]); pv.e[qq + 1] = f2bf(x[1]);
+                x = act_fast_f2(p.act, x);
+                if (has_d) x *= dact_fast_f2(p.dact_kind, vf2{bf2f(dv.e[qq]), bf2f(dv.e[qq + 1])});
+                const uint32_t di = (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + qq);
+                x *= vf2{drop_mult(dr, di), drop_mult(dr, di + 1u)};
+                if (has_a) x += vf2{bf2f(av.e[qq]), bf2f(av.e[qq + 1])};
+                ov.e[qq] = f2bf(x[0]); ov.e[qq + 1] = f2bf(x[1]);
               }
               *reinterpret_cast<PV8*>(C + (size_t)row * p.ldc + col) = ov;
               if (preact != nullptr) *reinterpret_cast<PV8*>(preact + (size_t)row * p.ld_preact + col) = pv;
