@@ -102,7 +102,7 @@ __device__ __forceinline__ float dact_fast_f(int act, float x) {
 // (murmur3 fmix32 with a golden-ratio pre-mix): plenty for a Bernoulli mask.
 struct Dropout {
   uint32_t key;     // seed ^ site mix
-  uint32_t thresh;  // drop if hash < thresh
+  uint32_t thresh;  // drop if the element's 16-bit field < thresh (p rounded to 1 / 65536)
   float scale;      // 1/(1-p)
   bool on;
 };
@@ -110,7 +110,7 @@ __device__ __forceinline__ Dropout make_dropout(const uint32_t* seed, uint32_t s
   Dropout d;
   d.on = (seed != nullptr) && (p > 0.0f);
   d.key = d.on ? (seed[0] * 0x9E3779B1u) ^ (site * 0x85EBCA77u + 0x165667B1u) : 0u;
-  d.thresh = d.on ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u;
+  d.thresh = d.on ? (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f) : 0u;
   d.scale = d.on ? 1.0f / (1.0f - p) : 1.0f;
   return d;
 }
@@ -118,11 +118,36 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
 }
+// One hash serves the element PAIR (2k, 2k + 1): low / high 16 bits.  The hash is three 32-bit integer multiplies (quarter rate)
+// and eight shifts / xors -- as much VALU time per element as the fast GELU -- and the GEMM epilogues, the LayerNorm and the
+// embedding kernels all walk consecutive elements: drop_mults below pays for it once per two elements.
 // multiplier to apply to element `idx` (0 or 1/(1-p)); 1 when dropout is off
 __device__ __forceinline__ float drop_mult(const Dropout& d, uint32_t idx) {
   if (!d.on) return 1.0f;
-  const uint32_t h = hash32((idx * 0x9E3779B1u) ^ d.key);
-  return h < d.thresh ? 0.0f : d.scale;
+  const uint32_t h = hash32(((idx >> 1) * 0x9E3779B1u) ^ d.key);
+  const uint32_t f = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+  return f < d.thresh ? 0.0f : d.scale;
+}
+// ... of the N consecutive elements idx .. idx + N - 1 (N even; one hash per pair when idx is even, which it is wherever rows have
+// an even length)
+template <int N> __device__ __forceinline__ void drop_mults(const Dropout& d, uint32_t idx, float (&m)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+  if (!d.on) {
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = 1.0f;
+    return;
+  }
+  if ((idx & 1u) == 0u) {
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+      const uint32_t h = hash32((((idx >> 1) + (uint32_t)k) * 0x9E3779B1u) ^ d.key);
+      m[2 * k] = (h & 0xffffu) < d.thresh ? 0.0f : d.scale;
+      m[2 * k + 1] = (h >> 16) < d.thresh ? 0.0f : d.scale;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; j++) m[j] = drop_mult(d, idx + (uint32_t)j);
+  }
 }
 
 // ---- reductions ------------------------------------------------------------------------------

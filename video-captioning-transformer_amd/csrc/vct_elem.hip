@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int N, int S, int d, con
     const float4 tv = trow[vi], pv = prow[vi];
     const float e[4] = {tv.x + pv.x, tv.y + pv.y, tv.z + pv.z, tv.w + pv.w};
     PackT<T, 4> o;
+    float dmv[4];
+    drop_mults<4>(dr, (uint32_t)n * (uint32_t)d + (uint32_t)(vi * 4), dmv);
 #pragma unroll
-    for (int j = 0; j < 4; j++) o.v[j] = from_f<T>(e[j] * drop_mult(dr, (uint32_t)n * (uint32_t)d + (uint32_t)(vi * 4 + j)));
+    for (int j = 0; j < 4; j++) o.v[j] = from_f<T>(e[j] * dmv[j]);
     *reinterpret_cast<PackT<T, 4>*>(x + (size_t)n * d + vi * 4) = o;
   }
 }
@@ -141,8 +143,10 @@ __device__ __forceinline__ void embed_bwd_light(int n, int N, int d, const int32
       if (on) {
         const int col = (c * 64 + lane) * VEC;
         const P v = *reinterpret_cast<const P*>(dx + (size_t)pos * d + col);
+        float dmv[VEC];
+        drop_mults<VEC>(dr, (uint32_t)pos * (uint32_t)d + (uint32_t)col, dmv);
 #pragma unroll
-        for (int j = 0; j < VEC; j++) acc[c][j] += to_f<T>(v.v[j]) * drop_mult(dr, (uint32_t)pos * (uint32_t)d + (uint32_t)(col + j));
+        for (int j = 0; j < VEC; j++) acc[c][j] += to_f<T>(v.v[j]) * dmv[j];
       }
     }
   };
@@ -293,9 +297,10 @@ __global__ __launch_bounds__(1024) void embed_bwd_kernel(int N, int d, int V, co
 #pragma unroll
           for (int u = 0; u < DEPTH; u++) {
             if (pos[u] >= 0) {
+              float dmv[VEC];
+              drop_mults<VEC>(dr, (uint32_t)pos[u] * (uint32_t)d + (uint32_t)(chunk * VEC), dmv);
 #pragma unroll
-              for (int j = 0; j < VEC; j++)
-                acc[j] += to_f<T>(v[u].v[j]) * drop_mult(dr, (uint32_t)pos[u] * (uint32_t)d + (uint32_t)(chunk * VEC + j));
+              for (int j = 0; j < VEC; j++) acc[j] += to_f<T>(v[u].v[j]) * dmv[j];
             }
           }
         }

@@ -434,8 +434,9 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         pv.e[q] = from_f<TO>(x[0]); pv.e[q + 1] = from_f<TO>(x[1]);
         x = act_fast_f2(p.act, x);
         if (has_d) x *= dact_fast_f2(p.dact_kind, vf2{to_f<TO>(dv.e[q]), to_f<TO>(dv.e[q + 1])});
-        const uint32_t di = (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q);
-        x *= vf2{drop_mult(dr, di), drop_mult(dr, di + 1u)};
+        float dm2[2];
+        drop_mults<2>(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + q), dm2);
+        x *= vf2{dm2[0], dm2[1]};
         if (has_a) x += vf2{to_f<TO>(av.e[q]), to_f<TO>(av.e[q + 1])};
         ov.e[q] = from_f<TO>(x[0]); ov.e[q + 1] = from_f<TO>(x[1]);
       }

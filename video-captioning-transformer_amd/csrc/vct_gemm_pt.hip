@@ -236,8 +236,9 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
                 pv.e[qq] = f2bf(x[0]); pv.e[qq + 1] = f2bf(x[1]);
                 x = act_fast_f2(p.act, x);
                 if (has_d) x *= dact_fast_f2(p.dact_kind, vf2{bf2f(dv.e[qq]), bf2f(dv.e[qq + 1])});
-                const uint32_t di = (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + qq);
-                x *= vf2{drop_mult(dr, di), drop_mult(dr, di + 1u)};
+                float dm2[2];
+                drop_mults<2>(dr, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + qq), dm2);
+                x *= vf2{dm2[0], dm2[1]};
                 if (has_a) x += vf2{bf2f(av.e[qq]), bf2f(av.e[qq + 1])};
                 ov.e[qq] = f2bf(x[0]); ov.e[qq + 1] = f2bf(x[1]);
               }

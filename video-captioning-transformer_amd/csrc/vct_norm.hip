@@ -42,9 +42,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* 
       const RV xv = *reinterpret_cast<const RV*>(x + (size_t)row * d + vi * VEC);
       RV rv;
       if (res != nullptr) rv = *reinterpret_cast<const RV*>(res + (size_t)row * d + vi * VEC);
+      float dmv[VEC];
+      drop_mults<VEC>(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC), dmv);
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
-        float v = to_f<T>(xv.v[j]) * drop_mult(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC + j));
+        float v = to_f<T>(xv.v[j]) * dmv[j];
         if (res != nullptr) v += to_f<T>(rv.v[j]);
         s[it][j] = v;
         sum += v;
@@ -148,9 +150,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
         const RV dv = *reinterpret_cast<const RV*>(dy + (size_t)row * d + vi * VEC);
         RV rv;
         if (res != nullptr) rv = *reinterpret_cast<const RV*>(res + (size_t)row * d + vi * VEC);
+        float dmv[VEC];
+        drop_mults<VEC>(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC), dmv);
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
-          const float m = drop_mult(dr, (uint32_t)row * (uint32_t)d + (uint32_t)(vi * VEC + j));
+          const float m = dmv[j];
           float s = to_f<T>(xv.v[j]) * m;
           if (res != nullptr) s += to_f<T>(rv.v[j]);
           const float h = (s - mean) * rstd;
