@@ -97,6 +97,36 @@ __device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __re
                                    (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
 }
 
+// The same instruction with its per-lane source address split into a part that is fixed for a whole output tile (byte offset of the
+// lane's 16 bytes at K offset 0: row clamp, row x leading dimension, swizzled chunk -- a 64-bit multiply) and a wave-uniform base
+// that moves with the K stage.  Recomputing the address per piece and stage cost the K loop of the persistent-tile kernel eight
+// vector instructions per piece, three of them quarter-rate multiplies: about as many VALU issue cycles per stage as its MFMAs.
+template <bool MC, int R, int NW>
+__device__ __forceinline__ uint32_t dma_piece_offset(long ld, int r0, int r_ext, int wave, int lane, int q) {
+  const int ci = q * NW + wave;
+  if constexpr (!MC) {
+    const int row = ci * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    return (uint32_t)(((long)min(r0 + row, r_ext - 1) * ld + c * 8) * 2);
+  } else {
+    constexpr int CPRW = R / 8, RPI = 64 / CPRW, NB = R / 16;
+    const int krow = ci * RPI + lane / CPRW;
+    const int pp = lane % CPRW;
+    const int b = (pp >> 1) ^ (krow & (NB - 1));
+    const int col = (b * 2 + (pp & 1)) * 8;
+    const int rlim = ((r_ext + 7) & ~7) - 8;
+    return (uint32_t)(((long)krow * ld + min(r0 + col, rlim)) * 2);
+  }
+}
+// base_k: the operand advanced to the stage (K-contiguous: base + k0; M/N-contiguous: base + k0 * ld), wave-uniform
+template <int NW>
+__device__ __forceinline__ void dma_piece_at(unsigned char* lds, const bf16_t* __restrict__ base_k, uint32_t off, int wave, int q) {
+  const int ci = q * NW + wave;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(base_k) + (size_t)off;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
+}
+
 // ragged last K tile: predicated 16-byte loads (zero fill) written into the same swizzled image
 struct alignas(16) V16b { uint32_t w[4]; };
 template <bool MC, int R, int NT>

@@ -25,7 +25,7 @@ struct alignas(16) PV8 { bf16_t e[8]; };
 
 // EPI = false: bias only, the row slab holds bf16 (one LDS pass per 128 rows); EPI = true: the slab holds fp32 and the store
 // phase applies the full epilogue on 8 consecutive columns per thread.
-template <int TA, int TB, int TM, int TN, bool EPI, int NSTG>
+template <int TA, int TB, int TM, int TN, bool EPI>
 __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0), KSPLIT = A_MC && B_MC;
   constexpr int NW = 8, NT = 512;
@@ -93,50 +93,36 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
   const bf16_t* addend = reinterpret_cast<const bf16_t*>(p.addend);
   const bf16_t* dact = reinterpret_cast<const bf16_t*>(p.dact);
 
-  // The flat list of (tile, K stage) steps of this workgroup.  NSTG LDS stages: step s computes from stage s % NSTG while the DMA
-  // of step s + NSTG - 1 is issued, so a load has NSTG - 1 steps of MFMA time to land (NSTG = 2: one step; NSTG = 3: two steps,
-  // waits are `vmcnt(pieces of the step in between)` instead of `vmcnt(0)`).  Measured (tools/gemm_pt_bench.py,
-  // VCT_GEMM_PT_STAGES=3): the deeper prefetch buys nothing -- 128 x 128 tiles (96 KB: one workgroup per CU instead of two)
-  // decoder QKV 14.2 -> 17.3 us, FFN1 19.6 -> 24.2, batch-1024 FFN1 66 -> 79; 64 x 128 tiles (72 KB, still two per CU) 22.0 ->
-  // 21.9 / 84 -> 87 -- so the K loop is not waiting for its operands (the CU's L2 -> LDS stream runs at 12-16 B/clk of the 54
-  // it can reach because the loop asks for no more); two stages stay the default.
-  struct Cur { int w, m0, n0, kt; bool valid; };
-  auto advance = [&](Cur& c) {
-    if (c.kt + 1 < nkt) { c.kt++; return; }
-    c.kt = 0; c.w += nxw;
-    if (c.w < w_end) item(c.w, c.m0, c.n0); else c.valid = false;
-  };
-  Cur c;
-  c.w = w_begin + slot; c.m0 = 0; c.n0 = 0; c.kt = 0; c.valid = c.w < w_end;
-  if (!c.valid) return;
-  item(c.w, c.m0, c.n0);
-  Cur pf = c;                                             // the step whose stage is issued next
-  int pend_next = 0;                                      // DMA instructions of this wave in flight for the step AFTER the current one
+  // Loop control kept OUT of the K stages: cycle stamps of single waves (a development build) put a stage of the first version -- a
+  // flat list of (tile, K stage) steps walked by two cursors -- at ~2100 cycles, of which the 16 MFMAs are 256: 170-260 cycles of
+  // scalar bookkeeping in front of the fragment reads, 290-460 behind the MFMAs (cursor advance, 64-bit stage pointers, buffer
+  // index), 90-600 at the barrier.  Now: nested loops, the next tile's coordinates and the lanes' DMA offsets once per tile,
+  // running stage pointers, and a branch-free stage body (DMA = true: the next stage always exists and is a full one; the ragged
+  // last K stage and the end of the work list take the DMA = false body): the hot loop is ONE basic block of 55 instructions per
+  // stage.  Measured: the same speed (batch-1024 linear1 60.2 -> 59.1 us, QKV 13.5 -> 15.0 / 12.2 -> 12.3) -- a stage still takes
+  // ~3400 cycles for two co-resident workgroups against 1024 of MFMA issue, ~800 of LDS traffic and ~1200 of L2 -> LDS stream: the
+  // three do not overlap because every wave of a workgroup reads its fragments right behind the barrier and issues its MFMAs
+  // right behind the reads (PMC: MFMA pipe 30 % busy, LDS 27 %, waves waiting 45 % of their cycles).  s_setprio around the MFMA
+  // groups: no change.  (Three LDS stages with loads two steps ahead, measured on the first version, bought nothing either.)
+  int w = w_begin + slot;
+  if (w >= w_end) return;
+  int m0 = 0, n0 = 0;
+  item(w, m0, n0);
+  uint32_t poff[NP];                                      // per-lane source offsets of the NP DMA pieces of a tile (dma_piece_offset)
+  auto tile_offsets = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int i = 0; i < NSTG - 1; i++) {
-    if (pf.valid) {
-      issue(pf.m0, pf.n0, pf.kt, i);
-      if (i == 1) pend_next = pf.kt < kt_full ? NP : 0;
-    }
-    advance(pf);
-  }
-  int buf = 0;
-  bool fresh = true;                                      // first step, or the step after an epilogue (its global stores / loads count too)
-  while (c.valid) {
-    const int m0 = c.m0, n0 = c.n0;
-    if (NSTG > 2 && !fresh && pend_next == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the current stage has landed
-    __builtin_amdgcn_s_barrier();                          // ... everyone's has; everyone is done with the stage issued into next
-    asm volatile("" ::: "memory");
-    fresh = false;
-    // the stage NSTG - 1 steps ahead (this tile's, or one of the first stages of the NEXT tile, which then fly under this tile's
-    // epilogue): a full stage goes by DMA, one instruction after each row tile's MFMAs; a ragged one takes the register path up front
-    const int tb = (buf + NSTG - 1) % NSTG;
-    const bool nx_any = pf.valid;
-    const bool nx_dma = nx_any && pf.kt < kt_full;
-    const int nx_m = pf.m0, nx_n = pf.n0, nx_kt = pf.kt;
-    if (nx_any && !nx_dma) issue(nx_m, nx_n, nx_kt, tb);
-    unsigned char* nb = lds + tb * STAGE;
+    for (int q = 0; q < NP; q++)
+      poff[q] = q < BM / 64 ? dma_piece_offset<A_MC, BM, NW>(p.lda, tm0, p.M, wave, lane, q)
+                            : dma_piece_offset<B_MC, BN, NW>(p.ldb, tn0, p.N, wave, lane, q - BM / 64);
+  };
+  tile_offsets(m0, n0);
+  issue(m0, n0, 0, 0);
+  const long a_step = A_MC ? (long)BK2 * p.lda : (long)BK2, b_step = B_MC ? (long)BK2 * p.ldb : (long)BK2;   // elements per K stage
+  // one K stage: fragments of stage `buf`, MFMAs, and (DMA) the four 1-KiB pieces of the stage at a_k / b_k into the other buffer,
+  // one after each row tile's MFMAs of the first k-step
+  auto stage = [&](auto DMA_, const int buf, const bf16_t* a_k, const bf16_t* b_k) {
+    constexpr bool DMA = decltype(DMA_)::value;
+    unsigned char* nb = lds + (buf ^ 1) * STAGE;
     const unsigned char* la = lds + buf * STAGE;
     const unsigned char* lb = la + BM * 128;
 #pragma unroll
@@ -151,20 +137,53 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         const int q = ks * TM + i;                         // DMA issue slot
-        if (q < NP && nx_dma) {
-          if (q < BM / 64) dma_piece<A_MC, BM, NW>(nb, A, p.lda, nx_m, p.M, nx_kt * BK2, wave, lane, q);
-          else dma_piece<B_MC, BN, NW>(nb + BM * 128, B, p.ldb, nx_n, p.N, nx_kt * BK2, wave, lane, q - BM / 64);
+        if constexpr (DMA) {
+          if (q < NP) {
+            if (q < BM / 64) dma_piece_at<NW>(nb, a_k, poff[q], wave, q);
+            else dma_piece_at<NW>(nb + BM * 128, b_k, poff[q], wave, q - BM / 64);
+          }
         }
       }
     }
-    if (NSTG > 2) pend_next = nx_dma ? NP : 0;             // with three stages the stage issued here is the one after next
-    const bool tile_done = c.kt == nkt - 1;
-    unsigned char* slab = lds + buf * STAGE;               // the stage just consumed is free until the next step issues into ...
-    advance(c); advance(pf);
-    buf = (buf + 1) % NSTG;
-    if (!tile_done) continue;
+  };
+  auto stage_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the current stage has landed
+    __builtin_amdgcn_s_barrier();                          // ... everyone's has; everyone is done with the other buffer
+    asm volatile("" ::: "memory");
+  };
+  int buf = 0;
+  for (; w < w_end; w += nxw) {
+    int m1 = 0, n1 = 0;
+    const bool have_next = w + nxw < w_end;
+    if (have_next) item(w + nxw, m1, n1);
+    const bf16_t* a_k = A + a_step;                        // stage 1 of this tile
+    const bf16_t* b_k = B + b_step;
+    int kt = 0;
+    const int kt_hot = min(nkt, kt_full) - 1;
+    for (; kt < kt_hot; kt++) {                            // hot loop, ONE body: the next stage is this tile's and a full one
+      stage_sync();
+      stage(std::true_type{}, buf, a_k, b_k);
+      a_k += a_step; b_k += b_step;
+      buf ^= 1;
+    }
+    for (; kt + 1 < nkt; kt++) {                           // (at most once) the next stage is the ragged last one: register path, up front
+      stage_sync();
+      issue(m0, n0, kt + 1, buf ^ 1);
+      stage(std::false_type{}, buf, a_k, b_k);
+      buf ^= 1;
+    }
+    // the tile's last stage: the NEXT tile's first stage flies under it and under the epilogue
+    stage_sync();
+    if (have_next) {
+      tile_offsets(m1, n1);
+      if (kt_full > 0) stage(std::true_type{}, buf, A, B);
+      else { issue(m1, n1, 0, buf ^ 1); stage(std::false_type{}, buf, A, B); }
+    } else {
+      stage(std::false_type{}, buf, A, B);
+    }
+    unsigned char* slab = lds + buf * STAGE;               // the stage just consumed is free until the next tile's second stage is issued
+    buf ^= 1;
     // ---- epilogue ----
-    fresh = true;
     float bj[TN][4];
     if constexpr (!EPI) {
 #pragma unroll
@@ -264,32 +283,28 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
-    // the next step's barrier (after its vmcnt wait) orders the last slab reads before the DMA that reuses this stage
+    m0 = m1; n0 = n1;
+    // the next stage's barrier (after its vmcnt wait) orders the last slab reads before the DMA that reuses this stage
   }
 }
 
-template <int TA, int TB, int TM, int TN, bool EPI, int NSTG> static int gpt_launch(const GemmP& p, hipStream_t st) {
-  constexpr int LDSB = NSTG * (32 * TM + 64 * TN) * 128;
+template <int TA, int TB, int TM, int TN, bool EPI> static int gpt_launch(const GemmP& p, hipStream_t st) {
+  constexpr int LDSB = 2 * (32 * TM + 64 * TN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   constexpr int per_cu = LDSB <= 80 * 1024 ? 2 : 1;
-  vct::launch(gemm_pt_kernel<TA, TB, TM, TN, EPI, NSTG>, dim3(per_cu * persistent_grid(st)), dim3(512), (size_t)LDSB, st, p);
+  vct::launch(gemm_pt_kernel<TA, TB, TM, TN, EPI>, dim3(per_cu * persistent_grid(st)), dim3(512), (size_t)LDSB, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
 
-template <int TA, int TB, int NSTG> static int gpt_dispatch_s(const GemmP& p, int tile, bool epi, hipStream_t st) {
-  if (tile == 0) return epi ? gpt_launch<TA, TB, 4, 2, true, NSTG>(p, st) : gpt_launch<TA, TB, 4, 2, false, NSTG>(p, st);     // 128 x 128
-  return epi ? gpt_launch<TA, TB, 2, 2, true, NSTG>(p, st) : gpt_launch<TA, TB, 2, 2, false, NSTG>(p, st);                    // 64 x 128
-}
 template <int TA, int TB> static int gpt_dispatch(const GemmP& p, int tile, bool epi, hipStream_t st) {
-  static const char* senv = getenv("VCT_GEMM_PT_STAGES");
-  const int stages = senv != nullptr ? atoi(senv) : 2;
-  return stages == 3 ? gpt_dispatch_s<TA, TB, 3>(p, tile, epi, st) : gpt_dispatch_s<TA, TB, 2>(p, tile, epi, st);
+  if (tile == 0) return epi ? gpt_launch<TA, TB, 4, 2, true>(p, st) : gpt_launch<TA, TB, 4, 2, false>(p, st);     // 128 x 128
+  return epi ? gpt_launch<TA, TB, 2, 2, true>(p, st) : gpt_launch<TA, TB, 2, 2, false>(p, st);                    // 64 x 128
 }
 
 // Eligibility + launch (called from vct_gemm after the skinny and the vocabulary kernels).  VCT_GEMM_PT: bit 0 = NT products,
@@ -315,6 +330,10 @@ int gemm_pt_try(const vct_gemm_desc* d, hipStream_t st, bool* used) {
   // faster alone (22.8 vs 27-33 us for linear2) and co-schedules better beside the second stream's weight-gradient GEMMs
   if (d->reserved != 100 && d->N < 1024) return VCT_OK;
   if ((d->ldc % 8) || ((uintptr_t)d->C & 15)) return VCT_OK;
+  {   // the DMA addresses are (wave-uniform base) + (32-bit per-lane byte offset)
+    const int64_t a_rows = d->ta ? d->K : d->M, b_rows = d->tb ? d->N : d->K;
+    if ((a_rows + 64) * d->lda * 2 >= (int64_t)1 << 32 || (b_rows + 64) * d->ldb * 2 >= (int64_t)1 << 32) return VCT_OK;
+  }
   if (d->preact && ((d->ld_preact % 8) || ((uintptr_t)d->preact & 15))) return VCT_OK;
   if (d->addend && ((d->ld_addend % 8) || ((uintptr_t)d->addend & 15))) return VCT_OK;
   if (d->dact_src && ((d->ld_dact % 8) || ((uintptr_t)d->dact_src & 15))) return VCT_OK;

@@ -8,37 +8,6 @@
 
 namespace vct {
 
-// The update of two elements.  sqrt, the division by the bias correction and the division by the denominator are ONE v_sqrt_f32,
-// one multiply by a precomputed reciprocal and ONE v_rcp_f32 (1 ulp each: the parameter moves by lr x (1 +- 2e-7) x ratio; against
-// torch.optim.Adam the result differs by at most the last bit, tests/test_model_gpu.py) instead of three correctly rounded
-// ten-instruction sequences; the rest runs through packed fp32 instructions.  The pass is HBM-bound by itself, but it runs beside
-// the encoder backward, whose kernels it competes with for VALU issue slots.
-struct AdamC { float decay, omb1, b2, omb2, inv_bc2s, eps, step_size; };
-__device__ __forceinline__ AdamC adam_consts(float lr, float b1, float b2, float eps, float wd, const int32_t* step) {
-  const float t = (float)(step[0] + 1);
-  const float bc1 = 1.0f - powf(b1, t);
-  const float bc2s = sqrtf(1.0f - powf(b2, t));
-  AdamC c;
-  c.decay = 1.0f - lr * wd; c.omb1 = 1.0f - b1; c.b2 = b2; c.omb2 = 1.0f - b2; c.inv_bc2s = 1.0f / bc2s; c.eps = eps;
-  c.step_size = lr / bc1;
-  return c;
-}
-__device__ __forceinline__ void adam_pair(vf2& w, const vf2 g, vf2& m, vf2& v, const AdamC& c) {
-  w = w * c.decay;
-  m = m + c.omb1 * (g - m);
-  v = c.b2 * v + (c.omb2 * g) * g;
-  const vf2 sq = {__builtin_amdgcn_sqrtf(v[0]), __builtin_amdgcn_sqrtf(v[1])};
-  const vf2 denom = sq * c.inv_bc2s + c.eps;
-  const vf2 r = {__builtin_amdgcn_rcpf(denom[0]), __builtin_amdgcn_rcpf(denom[1])};
-  w = w - c.step_size * (m * r);
-}
-__device__ __forceinline__ void adam_quad(float4& p, const float4& g, float4& m, float4& v, const AdamC& c) {
-  vf2 w0 = {p.x, p.y}, w1 = {p.z, p.w}, m0 = {m.x, m.y}, m1 = {m.z, m.w}, v0 = {v.x, v.y}, v1 = {v.z, v.w};
-  adam_pair(w0, vf2{g.x, g.y}, m0, v0, c);
-  adam_pair(w1, vf2{g.z, g.w}, m1, v1, c);
-  p = float4{w0[0], w0[1], w1[0], w1[1]}; m = float4{m0[0], m0[1], m1[0], m1[1]}; v = float4{v0[0], v0[1], v1[0], v1[1]};
-}
-
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, const int32_t* __restrict__ step,
@@ -46,14 +15,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   // hyper-parameters from DEVICE memory when given: a captured hipGraph / recorded launch list then follows the
   // learning-rate schedule (kernel arguments are frozen at capture time)
   if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
-  const AdamC c = adam_consts(lr, b1, b2, eps, wd, step);
+  const float t = (float)(step[0] + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2s = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const float decay = 1.0f - lr * wd;
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
     float4 mv = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
-    adam_quad(pv, gv, mv, vv, c);
+    float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float w = pp[j] * decay;
+      mp[j] = mp[j] + (1.0f - b1) * (gp[j] - mp[j]);
+      vp[j] = b2 * vp[j] + (1.0f - b2) * gp[j] * gp[j];
+      const float denom = sqrtf(vp[j]) / bc2s + eps;
+      w -= step_size * (mp[j] / denom);
+      pp[j] = w;
+    }
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
@@ -78,7 +60,11 @@ __global__ __launch_bounds__(256) void adam2d_kernel(float* __restrict__ p, cons
   constexpr int STR = 72;                                    // LDS row stride in elements (16-byte aligned rows)
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * STR];
   if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
-  const AdamC c = adam_consts(lr, b1, b2, eps, wd, step);
+  const float t = (float)(step[0] + 1);
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2s = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const float decay = 1.0f - lr * wd;
   const int tiles_c = cols / 64;
   const int r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64, tid = threadIdx.x;
   float4 pv[4], gv[4], mv[4], vv[4];
@@ -92,7 +78,16 @@ __global__ __launch_bounds__(256) void adam2d_kernel(float* __restrict__ p, cons
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int rl = (tid >> 4) + 16 * i, r = r0 + rl;
-    adam_quad(pv[i], gv[i], mv[i], vv[i], c);
+    float* pp = &pv[i].x; const float* gp = &gv[i].x; float* mp = &mv[i].x; float* vp = &vv[i].x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float w = pp[j] * decay;
+      mp[j] = mp[j] + (1.0f - b1) * (gp[j] - mp[j]);
+      vp[j] = b2 * vp[j] + (1.0f - b2) * gp[j] * gp[j];
+      const float denom = sqrtf(vp[j]) / bc2s + eps;
+      w -= step_size * (mp[j] / denom);
+      pp[j] = w;
+    }
     ushort4 o;
     o.x = f2bf(pv[i].x); o.y = f2bf(pv[i].y); o.z = f2bf(pv[i].z); o.w = f2bf(pv[i].w);
     *reinterpret_cast<ushort4*>(tile + rl * STR + (tid & 15) * 4) = o;

@@ -232,6 +232,8 @@ class FusedAdam(torch.optim.Optimizer):
         # 2-D weights with an eager transposed shadow inside the range (W_g^T): their own pass writes the transposed copy too
         fused = sorted(ps.eager_transposed_in(a, b), key=lambda x: x[2]) if bf else []
         fused = [f for f in fused if ps.params[f[0]].shape[1] % 64 == 0 and not (f[2] < self.skip[1] and f[3] > self.skip[0])]
+        if os.environ.get("VCT_ADAM2D", "1") == "0":      # A/B switch: transposed shadow by a transpose launch behind the flat pass
+            fused = []
 
         def flat_range(lo, hi):
             if hi <= lo:
