@@ -260,3 +260,29 @@ def test_shipped_width_fp32_batch1_decode_takes_the_batched_step():
             _compare_until_margin(ys, ref_ys, margins, 5e-5)
         else:
             _compare_until_margin(ys, ref_ys, margins, 0.15)
+
+
+def test_first_overlapped_step_leaves_exact_adam_moments():
+    """From zero moments the first step must leave m = (1 - b1) g and v = ((1 - b2) g) g of ITS OWN gradient, bitwise, for every
+    parameter of the caption path -- at the bench batch, where Adam on the decoder / vocabulary part runs beside the encoder
+    backward on the second stream.  Anything else means Adam read a gradient that was still being written, somebody else wrote the
+    moment buffers, or the optimizer's arithmetic is not repeatable under co-scheduling (a v_sqrt / v_rcp + packed-fp32 variant of
+    the kernel failed exactly this way: 16-lane groups of wrong first moments in generator.weight, a few per step)."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    mc = model_config_of(load_golden("cfgA_slices.npz"))
+    V = 30522
+    p = O.init_params(O.cfg_from_model_config(mc, V), seed=31)
+    f, mk, ids = O.synthetic_batch(256, 12, 512, 20, V, seed=5)
+    feats, mask, idt = _to_dev(f, mk, ids)
+    c1 = (torch.tensor(1.0) - torch.tensor(0.9)).to(DEV)
+    c2 = (torch.tensor(1.0) - torch.tensor(0.999)).to(DEV)
+    for drop in (0.3, 0.0, 0.0):
+        mm = build_model(dict(mc, dropout=drop), V, DEV, torch.bfloat16, p)
+        mm.train(); mm._seed.fill_(99)
+        opt = FusedAdam(mm, lr=1e-4)
+        CaptionTrainer(mm, opt, launch_list=True).step(feats, mask, idt)
+        torch.cuda.synchronize()
+        e = mm.caption_param_end
+        g = mm.flat_grads[:e]
+        assert torch.equal(opt.exp_avg[:e], g * c1)
+        assert torch.equal(opt.exp_avg_sq[:e], (g * c2) * g)
