@@ -320,6 +320,33 @@ def test_two_models_in_one_process_keep_their_own_recordings():
     assert torch.equal(torch.cat(losses), lref) and torch.equal(a.flat_params, ref)
 
 
+def test_two_models_training_alternately_equal_their_solo_runs():
+    """Two models TRAINING in one process, one recorded step each in turn: neither may see the other's state -- in particular the
+    token-embedding gradient of the single-GPU fast path re-zeroes only the rows of the ids its own previous step used, which a
+    workspace shared between the models got wrong (a replay zeroed the rows of the OTHER model's batch)."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    solo = {}
+    for seed in (7, 11):
+        m = _model(seed=seed)
+        m._seed.fill_(1234 + seed)
+        tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), launch_list=True)
+        for k in range(5):
+            tr.step(*_batch(100 + k + seed))
+        torch.cuda.synchronize()
+        solo[seed] = m.flat_params.clone()
+    ms, trs = {}, {}
+    for seed in (7, 11):
+        ms[seed] = _model(seed=seed)
+        ms[seed]._seed.fill_(1234 + seed)
+        trs[seed] = CaptionTrainer(ms[seed], FusedAdam(ms[seed], lr=1e-3), launch_list=True)
+    for k in range(5):
+        for seed in (7, 11):
+            trs[seed].step(*_batch(100 + k + seed))
+    torch.cuda.synchronize()
+    for seed in (7, 11):
+        assert torch.equal(ms[seed].flat_params, solo[seed]), seed
+
+
 @pytest.mark.parametrize("executor", ["list", "graph"])
 def test_replay_follows_weights_loaded_outside_the_optimizer(executor):
     """load_state_dict between two replayed steps (restoring the best checkpoint, train.py:214-216): the replayed step must

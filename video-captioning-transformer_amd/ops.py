@@ -306,7 +306,9 @@ def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, excl
     V = dtable.shape[0]
     incremental = False
     if id_ws is None:
-        key = (V, dx.device)
+        # one workspace per gradient table: it remembers the ids of the LAST call into that table (what the next incremental call
+        # zeroes) -- shared between two models it made a replayed step of one zero the rows of the other's batch
+        key = (V, dx.device, dtable.data_ptr())
         ent = _embed_ws.get(key)
         need = 2 * V + 4 + max(B * S, 65536)
         if ent is None or ent[0].numel() < need:
