@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) { st[t][r] = expf(st[t][r] - m); l += st[t][r]; }
+      for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
     l = red4_sum(l);
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int qq = qt * 16 + i;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
             float pv = 0.0f, dv = 0.0f, pdv = 0.0f;
             if (qt < LQT && qq < p.Lq && !key_masked(p, kp_row, qq, kk)) {
               const float mult = drop_mult(dr, (uint32_t)((blockIdx.x * p.Lq + qq) * p.Lk + kk));
-              pv = expf(s[r] * scale - stat_m[qq]) * stat_i[qq];
+              pv = attn_exp<T>(s[r] * scale - stat_m[qq]) * stat_i[qq];
               pdv = pv * mult;
               dv = pv * (dp[r] * mult - stat_d[qq]) * scale;
             }

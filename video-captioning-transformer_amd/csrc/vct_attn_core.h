@@ -6,6 +6,14 @@
 
 namespace vct {
 
+// softmax exponential: libm's expf (range reduction + polynomial, ~25 vector instructions, on the critical path of a latency-bound
+// one-wave kernel) only in the fp32 parity mode; the bf16 path takes v_exp_f32 (1 ulp of 2^x: far below a bf16 ulp of P)
+template <typename T> __device__ __forceinline__ float attn_exp(float x) {
+  if constexpr (sizeof(T) == 2) return __expf(x);
+  else return expf(x);
+}
+
+
 struct AttnP {
   int B, H, Lq, Lk, hd, causal;
   const void* q; long ldq;
@@ -218,7 +226,7 @@ __device__ __forceinline__ void attn_fwd_wave(const AttnP& p, const int b, const
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) { st[t][r] = expf(st[t][r] - m); l += st[t][r]; }
+      for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
     l = red4_sum(l);
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int qq = qt * 16 + i;
