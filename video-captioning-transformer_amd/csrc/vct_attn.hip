@@ -67,9 +67,14 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
     if (m == -INFINITY) m = 0.0f;
     float l = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 4; t++) {           // key tiles beyond Lk hold -inf: nothing to exponentiate, hash or scale there
+      if (t < LKT) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
+        for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
+      } else {
+        st[t] = f32x4{0, 0, 0, 0};
+      }
+    }
     l = red4_sum(l);
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int qq = qt * 16 + i;
@@ -90,12 +95,14 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
                                                           dOs[(qt * 16 + i) * C::STR + k4 * 4 + g], dpt[t], 0, 0, 0);
         }
       }
+      if (t < LKT) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int kk = t * 16 + g * 4 + r;
-        st[t][r] *= inv;                                                       // P
-        dpt[t][r] *= drop_mult(dr, (uint32_t)((blockIdx.x * p.Lq + qq) * p.Lk + kk));  // dP = dPd * M
-        dsum += dpt[t][r] * st[t][r];
+        for (int r = 0; r < 4; r++) {
+          const int kk = t * 16 + g * 4 + r;
+          st[t][r] *= inv;                                                       // P
+          dpt[t][r] *= drop_mult(dr, (uint32_t)((blockIdx.x * p.Lq + qq) * p.Lk + kk));  // dP = dPd * M
+          dsum += dpt[t][r] * st[t][r];
+        }
       }
     }
     dsum = red4_sum(dsum);

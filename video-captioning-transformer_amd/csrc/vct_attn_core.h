@@ -224,18 +224,25 @@ __device__ __forceinline__ void attn_fwd_wave(const AttnP& p, const int b, const
     if (m == -INFINITY) m = 0.0f;
     float l = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 4; t++) {           // key tiles beyond Lk hold -inf: nothing to exponentiate, hash or scale there
+      if (t < LKT) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
+        for (int r = 0; r < 4; r++) { st[t][r] = attn_exp<T>(st[t][r] - m); l += st[t][r]; }
+      } else {
+        st[t] = f32x4{0, 0, 0, 0};
+      }
+    }
     l = red4_sum(l);
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
     const int qq = qt * 16 + i;
 #pragma unroll
     for (int t = 0; t < 4; t++)
+      if (t < LKT) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int kk = t * 16 + g * 4 + r;
-        st[t][r] *= inv * drop_mult(dr, (uint32_t)((bh * p.Lq + qq) * p.Lk + kk));
+        for (int r = 0; r < 4; r++) {
+          const int kk = t * 16 + g * 4 + r;
+          st[t][r] *= inv * drop_mult(dr, (uint32_t)((bh * p.Lq + qq) * p.Lk + kk));
+        }
       }
     // O tile = P V
     f32x4 ot[DT];
