@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Assemble profiles/r<NN>_* from the scratch directory of one evidence pass on the GPU box (see profiles/README.md for the command
+that fills it): bench line, rocprofv3 summaries (list executor + eager timeline), per-kernel PMC table and the HBM-traffic JSON that
+bench.py reports as roofline.traffic.   python tools/collect_evidence.py gpurun_out/<dir> gpurun_out/<tag>_step r03"""
+import json
+import os
+import re
+import shutil
+import sys
+
+src, step, rnd = sys.argv[1].rstrip("/") + "/", sys.argv[2], sys.argv[3]
+P = lambda n: os.path.join("profiles", f"{rnd}_{n}")
+
+
+def last_json(path):
+    return [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
+
+
+open(P("bench_n1.json"), "w").write(last_json(src + "bench_n1.json") + "\n")
+open(P("bench_profiled.json"), "w").write(last_json(src + "bench_profiled.json") + "\n")
+oc = [l for l in open(src + "other_configs.jsonl").read().splitlines() if l.startswith("{")]
+open(P("other_configs.jsonl"), "w").write("\n".join(oc) + "\n")
+shutil.copy(src + "pmc_per_kernel.txt", P("pmc_bench_per_kernel.txt"))
+shutil.copy(src + "gpu_tests.txt", P("gpu_tests.txt"))
+shutil.copy(src + "bench_list_kernel_summary.txt", P("bench_kernel_summary.txt"))
+shutil.copy(step + "_kernel_summary.txt", P("bench_kernel_summary_eager.txt"))
+shutil.copy(step + "_timeline.txt", P("step_timeline.txt"))
+
+rows = {}
+for l in open(src + "pmc_per_kernel.txt"):
+    m = re.match(r"(.*\]) +(\d+) +([\d.]+) +(.*)$", l.rstrip())
+    if m:
+        c = dict(kv.split("=") for kv in m.group(4).split())
+        rows[m.group(1).strip()] = {"calls": int(m.group(2)), "avg_us": float(m.group(3)), **{k: float(v) for k, v in c.items()}}
+kb = lambda x: int(round(x * 1024))
+old = json.load(open(P("roofline_traffic.json")))
+
+
+def ent(key, name, alg):
+    r = rows[key]
+    f, w = kb(r["FETCH_SIZE"] * 2), kb(r["WRITE_SIZE"])
+    return {"kernel": old[name]["kernel"], "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "algorithmic_min_bytes": alg,
+            "avg_us_profiled": r["avg_us"], "l2_hit_rate": round(r["TCC_HIT"] / (r["TCC_HIT"] + r["TCC_MISS"]), 3),
+            "mfma_busy_cycles": r["SQ_VALU_MFMA_BUSY_CYCLES"], "gui_active_cycles": r["GRBM_GUI_ACTIVE"]}
+
+
+def find(prefix):
+    ks = [k for k in rows if k.startswith(prefix)]
+    return max(ks, key=lambda k: rows[k]["avg_us"] * rows[k]["calls"])
+
+
+red = rows[find("splitk_reduce_kernel<bf16>")]
+dx = ent(find("gemm256_kernel<0, 1, float>"), "gen_dx", 333000000)
+dx["reduce_fetch_bytes"], dx["reduce_write_bytes"] = kb(red["FETCH_SIZE"] * 2), kb(red["WRITE_SIZE"])
+dx["hbm_bytes"] += dx["reduce_fetch_bytes"] + dx["reduce_write_bytes"]
+dx["round2"] = old["gen_dx"].get("round2", "")
+ls = rows[find("sce_loss_kernel<bf16")]
+out = {"_source": old["_source"].split("calibrated in the same run")[0] +
+       f"calibrated in the same run on sce_loss_kernel: 2 x {ls['FETCH_SIZE']:.4g} KB = {ls['FETCH_SIZE'] * 2 * 1024 / 1e6:.1f} MB fetched / "
+       f"{ls['WRITE_SIZE']:.4g} KB = {ls['WRITE_SIZE'] * 1024 / 1e6:.1f} MB written against the 297.0 MB of bf16 logits it reads and the 297.0 MB gradient it writes",
+       "gen_fwd": ent(find("gemm256_kernel<0, 1, bf16>"), "gen_fwd", 333000000), "gen_dx": dx,
+       "gen_dw": ent(find("gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 364500000),
+       "sce_loss": ent(find("sce_loss_kernel<bf16"), "sce_loss", 593952768), "adam": ent(find("adam_kernel"), "adam", 0),
+       "adam2d": ent(find("adam2d_kernel"), "adam2d", 0), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048))}
+json.dump(out, open(P("roofline_traffic.json"), "w"), indent=1)
+d = json.loads(last_json(src + "bench_n1.json"))
+print(f"{d['value']:.0f} samples/s, {d['ms_per_step']} ms/step; roofline {d['roofline']['kernel_tag']} {d['roofline']['frac']}; "
+      f"north_star {d['north_star']['ms']} ms; decode {d['decode']['batch1']['us_per_step_replay_only']} / "
+      f"{d['decode']['batch128']['us_per_step_replay_only']} us")
+for k in ("gen_fwd", "gen_dx", "gen_dw", "sce_loss"):
+    print(k, round(out[k]["hbm_bytes"] / 1e6, 1), "MB HBM-side,", round(out[k]["hbm_bytes"] / max(out[k]["algorithmic_min_bytes"], 1), 2), "x algorithmic")
