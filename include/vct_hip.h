@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 6
+#define VCT_ABI_VERSION 7
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -192,6 +192,55 @@ typedef struct vct_linear_ln_desc {
 } vct_linear_ln_desc;
 int vct_linear_ln_supported(int dtype, int d, int K);
 int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sample-stationary Transformer layer forward (bf16): ONE launch = one whole encoder / decoder layer (and, with last != 0,
+ * the stack-final LayerNorm); one 512-thread workgroup per SAMPLE keeps that sample's rows in LDS for the whole layer and
+ * streams the layer's weights from L2 straight into MFMA operand registers (csrc/vct_layer_ss.hip).
+ * replaces: nn.TransformerEncoderLayer.forward (torch nn/modules/transformer.py:951-982) / nn.TransformerDecoderLayer.forward
+ * (:1143-1199) as built at MMEncoder.py:236-238 / CapDecoder.py:18-20 and run by MMEncoder.py:274 / CapDecoder.py:49-52
+ * (post-norm, gelu / relu, eps 1e-5; nn.MultiheadAttention = torch nn/functional.py:6206-6640), plus the final
+ * nn.LayerNorm of the stack (MMEncoder.py:238, CapDecoder.py:20) -- i.e. the vct_gemm / vct_attn_fwd / vct_add_ln_fwd /
+ * vct_add_ln_ln_fwd launches of one layer on the unfused path.  It SAVES exactly what those save (qkv, o, a, y, mean, rstd,
+ * cross q / kv / o / a, pre-activation, dropped activation, f) and draws the same dropout counter streams
+ * (site_*: attention probabilities, residual dropouts, feed-forward dropout), so the unfused backward kernels run behind it.
+ *   x bf16 [B*L, 512] layer input; mem bf16 [B*Lm, 512] (decoder layers; NULL = encoder layer: no cross-attention block,
+ *   n2 unused).  Self-attention masks as vct_attn_desc (causal; key_pad + key_pad_shift; key_ids / pad_id).
+ *   wpk: the layer's weights packed in STREAM ORDER by vct_ss_pack -- 64-KiB chunks (one 512-row block x 64 K columns of a
+ *   weight, as 8 waves x 8 MFMA fragments of 1 KiB), blocks in consumption order:
+ *     in_proj rows [0,512) [512,1024) [1024,1536) | out_proj | (decoder: cross in_proj rows [0,512) | [512,1024) [1024,1536) |
+ *     cross out_proj) | for j < ff/512: linear1 rows [512j, 512j+512) , linear2 columns [512j, 512j+512)
+ *   each block 8 chunks (K = 512); nchunks = vct_layer_ss_stream_chunks(ff, cross).
+ * vct_layer_ss_supported: bf16, d = 512, 8 heads of 64, ff a multiple of 512, L <= 32, Lm <= 16 (Lm = 0: encoder layer).
+ * vct_ss_pack: segs[i] = rows 0..511 x columns 0..64*nchunks-1 of the bf16 matrix at `w` (leading dimension ldw; the caller
+ *   offsets `w` to the block) -> chunks dst_chunk .. dst_chunk+nchunks-1 of `dst`.  One launch per 48 segments.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_ss_norm { const float* gamma; const float* beta; void* y; float* mean; float* rstd; } vct_ss_norm;
+typedef struct vct_layer_ss_desc {
+  int32_t dtype, B, L, Lm, d, H, ff, act;
+  int32_t last, causal, key_pad_shift, reserved;
+  const void* wpk; int64_t nchunks;
+  const void* x; const void* mem;
+  const float* b_qkv; const float* b_o;
+  void* qkv; void* o; void* a;
+  vct_ss_norm n1;
+  const float* b_cq; const float* b_ckv; const float* b_co;
+  void* cq; void* ckv; void* co; void* ca;
+  vct_ss_norm n2;
+  const float* b1; const float* b2;
+  void* hpre; void* h; void* f;
+  vct_ss_norm n3;
+  vct_ss_norm nf;
+  const uint8_t* key_pad; const int64_t* key_ids; int64_t key_ids_bs; int64_t pad_id;
+  const uint32_t* seed; float p_drop;
+  uint32_t site_sa, site_n1, site_ca, site_n2, site_ff, site_n3;
+  uint32_t pad0;
+} vct_layer_ss_desc;
+typedef struct vct_ss_pack_seg { const void* w; int64_t ldw; int32_t nchunks; int32_t reserved; int64_t dst_chunk; } vct_ss_pack_seg;
+int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm);
+int64_t vct_layer_ss_stream_chunks(int ff, int cross);
+int vct_ss_pack(const vct_ss_pack_seg* segs, int nseg, void* dst, void* stream);
+int vct_layer_ss_fwd(const vct_layer_ss_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).

@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 7
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -82,13 +82,38 @@ def test_descriptor_structs_match_the_c_header(tmp_path):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vct_gemm_desc), offsetof(vct_gemm_desc, workspace), offsetof(vct_gemm_desc, tile_counters),
          sizeof(vct_attn_desc), offsetof(vct_attn_desc, d_o), offsetof(vct_attn_desc, q_bs));
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_desc), offsetof(vct_layer_ss_desc, wpk), offsetof(vct_layer_ss_desc, n2),
+         offsetof(vct_layer_ss_desc, key_pad), offsetof(vct_layer_ss_desc, site_n3), sizeof(vct_ss_pack_seg), offsetof(vct_ss_pack_seg, dst_chunk));
   return 0;
 }''')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     G, A = _lib.GemmDesc, _lib.AttnDesc
-    assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset]
+    S, P = _lib.LayerSsDesc, _lib.SsPackSeg
+    assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset,
+                   ctypes.sizeof(S), S.wpk.offset, S.n2.offset, S.key_pad.offset, S.site_n3.offset, ctypes.sizeof(P), P.dst_chunk.offset]
+
+
+def test_layer_ss_entry_points_validate_arguments(lib_path):
+    """Sample-stationary layer forward (csrc/vct_layer_ss.hip): shape predicate, stream length and argument errors as codes."""
+    from vct_amd import _lib
+    lib = _lib.load()
+    assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 19, 13) == 1
+    assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 13, 0) == 1
+    assert lib.vct_layer_ss_supported(_lib.F32, 512, 8, 2048, 19, 13) == 0          # parity mode stays on the unfused kernels
+    assert lib.vct_layer_ss_supported(_lib.BF16, 768, 8, 2048, 19, 13) == 0
+    assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 33, 13) == 0 and lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 19, 17) == 0
+    assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 1000, 19, 13) == 0
+    assert lib.vct_layer_ss_stream_chunks(2048, 0) == 96 and lib.vct_layer_ss_stream_chunks(2048, 1) == 128     # 6.3 MB / 8.4 MB of bf16
+    assert lib.vct_layer_ss_fwd(None, None) == -1
+    d = _lib.LayerSsDesc()
+    d.dtype, d.B, d.L, d.d, d.H, d.ff = _lib.BF16, 4, 13, 512, 8, 2048
+    d.nchunks = 96
+    assert lib.vct_layer_ss_fwd(d, None) == -1                                      # null operands
+    d.nchunks = 95
+    assert lib.vct_layer_ss_fwd(d, None) == -2                                      # stream length does not match the layer
+    assert lib.vct_ss_pack(None, 1, None, None) == -1
 
 
 def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):

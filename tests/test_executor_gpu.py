@@ -347,6 +347,39 @@ def test_two_models_training_alternately_equal_their_solo_runs():
         assert torch.equal(ms[seed].flat_params, solo[seed]), seed
 
 
+def test_exclusive_gradient_zeroing_is_per_engine():
+    """Trainer A (single GPU, fused optimizer) makes ITS decoder engine the exclusive writer of its gradient buffer, so its
+    token-embedding gradient re-zeroes only the rows of its previous batch.  A second model B in the same process whose
+    gradient table is also written by somebody else (in-place accumulation / averaging between backward calls) must keep the
+    full zero-fill: the flag is an attribute of A's engine, not of the class."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    solo = _model(seed=7); solo._seed.fill_(77)
+    tr = CaptionTrainer(solo, FusedAdam(solo, lr=1e-3), launch_list=True)
+    for k in range(4):
+        tr.step(*_batch(100 + k))
+    torch.cuda.synchronize()
+    a = _model(seed=7); a._seed.fill_(77)
+    b = _model(seed=11, dropout=0.0)
+    tra = CaptionTrainer(a, FusedAdam(a, lr=1e-3), launch_list=True)
+    assert a.cap_decoder._engine().exclusive_grads is True and b.cap_decoder._engine().exclusive_grads is False
+    key = "cap_decoder.tgt_to_emb.weight"
+    grads = []
+    for k in range(4):
+        tra.step(*_batch(100 + k))
+        fb, mb, ib = _batch(900)                       # B: the SAME batch every time, reference call sequence (train.py:123-125)
+        b.zero_grad(set_to_none=False)
+        loss = b([fb], [mb], ib)
+        loss.backward()
+        grads.append(b._ps.g[key].clone())
+        b._ps.g[key].add_(1.0)                         # somebody else writes B's table (every row, also rows no batch touches)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_params, solo.flat_params)
+    for g in grads[1:]:
+        assert torch.equal(g, grads[0])                # B's backward re-zeroed ALL rows each time
+    used = torch.zeros(VOCAB, dtype=torch.bool, device=DEV); used[_batch(900)[2][:, :-1].reshape(-1)] = True
+    assert float(grads[0][~used].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("executor", ["list", "graph"])
 def test_replay_follows_weights_loaded_outside_the_optimizer(executor):
     """load_state_dict between two replayed steps (restoring the best checkpoint, train.py:214-216): the replayed step must

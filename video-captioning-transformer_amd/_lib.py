@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -51,6 +51,24 @@ class LinearLnDesc(C.Structure):
                 ("rows_per_wg", i32), ("reserved", i32)]
 
 
+class SsNorm(C.Structure):
+    _fields_ = [("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp)]
+
+
+class LayerSsDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("L", i32), ("Lm", i32), ("d", i32), ("H", i32), ("ff", i32), ("act", i32),
+                ("last", i32), ("causal", i32), ("key_pad_shift", i32), ("reserved", i32),
+                ("wpk", vp), ("nchunks", i64), ("x", vp), ("mem", vp), ("b_qkv", vp), ("b_o", vp), ("qkv", vp), ("o", vp), ("a", vp),
+                ("n1", SsNorm), ("b_cq", vp), ("b_ckv", vp), ("b_co", vp), ("cq", vp), ("ckv", vp), ("co", vp), ("ca", vp),
+                ("n2", SsNorm), ("b1", vp), ("b2", vp), ("hpre", vp), ("h", vp), ("f", vp), ("n3", SsNorm), ("nf", SsNorm),
+                ("key_pad", vp), ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64), ("seed", vp), ("p_drop", f32),
+                ("site_sa", u32), ("site_n1", u32), ("site_ca", u32), ("site_n2", u32), ("site_ff", u32), ("site_n3", u32), ("pad0", u32)]
+
+
+class SsPackSeg(C.Structure):
+    _fields_ = [("w", vp), ("ldw", i64), ("nchunks", i32), ("reserved", i32), ("dst_chunk", i64)]
+
+
 class DecodeGemvDesc(C.Structure):
     _fields_ = [("wdtype", i32), ("B", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i64), ("bias", vp), ("pro", i32), ("act", i32),
                 ("x_in", vp), ("ld_x", i64), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp),
@@ -88,6 +106,10 @@ _SIGS = {
     "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), vp]),
+    "vct_layer_ss_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vct_layer_ss_stream_chunks": (i64, [C.c_int, C.c_int]),
+    "vct_ss_pack": (C.c_int, [C.POINTER(SsPackSeg), C.c_int, vp, vp]),
+    "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), vp]),
     "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vct_linear_ln_fwd": (C.c_int, [C.POINTER(LinearLnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),

@@ -398,7 +398,9 @@ __global__ __launch_bounds__(DB_THREADS) void decode_gen_kernel(const DbP p) {
     const f32x2 pr = {bv, __int_as_float(bi)};
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.sel_ws + 2 * blockIdx.x), __builtin_bit_cast(unsigned long long, pr),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the write-through store has completed (cf. the split-K reduce of vct_gemm_bf16_kernel.h)
+    // the pair is an sc1 (write-through) store and the last workgroup reads it with sc1 loads: what orders it before the ticket is
+    // the store's acknowledgement, i.e. vmcnt(0) -- a workgroup-scope fence emits no wait on gfx950 (MI355X_MICROARCH: handoff-flag)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
@@ -438,7 +440,9 @@ __global__ __launch_bounds__(DB_THREADS) void decode_gen_kernel(const DbP p) {
 using namespace vct;
 
 extern "C" int vct_decode_block_supported(int dtype, int d, int H, int ff, int Lk) {
-  return (dtype == VCT_BF16 && d == DB_DMAX && H * DB_HD == d && ff >= DB_HD && ff % DB_HD == 0 && Lk >= 1 && Lk <= DB_LMAX) ? 1 : 0;
+  // ff / 64 feed-forward workgroups each publish one partial vector: the consumer's prologue sums at most DB_PMAX of them
+  return (dtype == VCT_BF16 && d == DB_DMAX && H * DB_HD == d && H <= DB_PMAX && ff >= DB_HD && ff % DB_HD == 0 && ff <= DB_PMAX * DB_HD &&
+          Lk >= 1 && Lk <= DB_LMAX) ? 1 : 0;
 }
 
 extern "C" int vct_decode_block(const vct_decode_block_desc* q, void* stream) {

@@ -549,7 +549,9 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   // counters live in the caller's zero-initialised workspace head and are left zero again.
   if (part && p.counters != nullptr) {
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's write-through partial stores have completed
+    // this wave's write-through (sc1) partial stores must be acknowledged before the ticket: a workgroup-scope fence emits no vmcnt
+    // wait on gfx950 (non-tgsplit), so wait explicitly (MI355X_MICROARCH "handoff-flag": sc1 payload -> vmcnt(0) -> flag)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
       s_last = (__hip_atomic_fetch_add(p.counters + wgid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.split - 1) ? 1 : 0;

@@ -1,0 +1,653 @@
+// Sample-stationary Transformer layer forward for short sequences on gfx950 (bf16 throughput mode, training or eval).
+//
+//     ONE launch = ONE whole nn.TransformerEncoderLayer / nn.TransformerDecoderLayer (+ optionally the stack-final LayerNorm)
+//     ONE 512-thread workgroup = ONE sample: its <= 32 token rows stay in LDS from the layer input to the layer output
+//
+// replaces, per layer, the 9-14 launches of the unfused schedule (engine.py: _attn_ln_fwd / _ffn_fwd / _ln_fwd): in-projection GEMM(s),
+// attention core, out_proj GEMM, add + LayerNorm, cross-attention likewise, linear1 (+GELU, dropout), linear2, add + LayerNorm --
+// i.e. torch nn/modules/transformer.py:951-982 (encoder layer) and :1143-1199 (decoder layer) as built at MMEncoder.py:236-238 and
+// CapDecoder.py:18-20, with nn.MultiheadAttention = torch nn/functional.py:6206-6640.
+//
+// Why this shape (tools/ss_probe.hip).  At cfg-B a layer is ~10 dependent products of 10 GFLOP: 4 us of
+// MFMA work each behind 14 us of launch + cold first fetch + epilogue + drain, and no tiling removes the dependency chain.  A sample's
+// rows, however, depend on no other sample: with B = 256 samples on 256 CUs every CU can run its sample through the WHOLE layer without
+// ever meeting another workgroup -- no kernel boundary, no grid barrier, no flag.  What it pays instead is weight traffic: each
+// workgroup streams all of the layer's bf16 weights (8.4 MB decoder / 6.3 MB encoder layer) from its XCD's L2 straight into MFMA
+// operand registers, at the L2 -> CU rate of one CU.  That rate is 15 B/clk/CU when the fragments are gathered from the [out, in]
+// row-major matrix (16 rows x 64 B per wave instruction) and 48 B/clk/CU when the weights are pre-packed in STREAM ORDER -- the exact
+// sequence of 1-KiB wave fragments the kernel consumes, so that the eight waves of a workgroup read 64 KB contiguous per K chunk and
+// the whole layer is one sequential stream (vct_ss_pack: a private second shadow of the layer weights, rewritten behind the
+// optimizer).  Measured with MFMAs, epilogue stores and product barriers in the loop: 86 us per decoder layer, 58 us per encoder layer,
+// 280 us for the 2 + 2 stack, against 440 us of GEMM + attention + LayerNorm launches today.  The MFMA pipe idles > 50 % (rows are padded
+// 19 -> 32, and the stream is the bound): the design buys latency, not arithmetic efficiency.
+//
+// Work split inside the workgroup: a product out[32, N] = A[32, K] W[N, K]^T is walked in 512-column blocks; wave w owns columns
+// w*64 .. w*64+63 of the block (4 MFMA column tiles x 2 row tiles), A fragments come from the LDS panel of the previous product,
+// W fragments from the stream (double-buffered one 64-deep K chunk ahead, ACROSS product boundaries: the stream does not depend on
+// data).  The MFMA operands are swapped (D^T = W X^T) so that a lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte LDS
+// stores in the epilogue.  Everything the unfused backward kernels read (qkv, o, a, LayerNorm statistics, pre-activation, dropped
+// activation, ...) is first completed in an LDS panel and then copied to HBM with 16-byte row-contiguous stores by all 512 threads;
+// the dropout counter streams are those of the unfused kernels, so the unfused backward runs unchanged behind this forward.
+#include "vct_attn_core.h"
+
+namespace vct {
+
+constexpr int SS_D = 512, SS_H = 8, SS_HD = 64, SS_NW = 8, SS_NT = 512;
+constexpr int SS_PSTR = SS_D + 8;                  // row stride (bf16 elements) of a [32][512] panel
+constexpr int SS_SLOT = 32 * SS_PSTR * 2;          // 33,280 B
+constexpr int SS_QSTR = 3 * SS_D + 8;              // q | k | v panel (self-attention): 32 x 1544 bf16 = 3 slots
+constexpr int SS_KVSTR = 2 * SS_D + 8;             // k | v panel of the memory (cross-attention): 16 x 1032 bf16 = 1 slot
+constexpr int SS_R0 = 0, SS_R1A = SS_SLOT, SS_R1B = 2 * SS_SLOT, SS_R1C = 3 * SS_SLOT;
+constexpr int SS_RM = 4 * SS_SLOT;                 // memory rows of this sample: 16 x 520 bf16
+constexpr int SS_RED = SS_RM + 16 * SS_PSTR * 2;   // LayerNorm partials: 2 x [8 waves][32 rows] fp32
+constexpr int SS_LDS = SS_RED + 2 * SS_NW * 32 * 4;
+constexpr long SS_CHUNK = 32768;                   // bf16 elements per K chunk of the stream (64 KiB: 8 waves x 8 fragments x 1 KiB)
+static_assert(SS_LDS <= 160 * 1024, "LDS budget");
+static_assert(32 * SS_QSTR * 2 <= 3 * SS_SLOT && 16 * SS_KVSTR * 2 <= SS_SLOT, "panel slots");
+
+struct SsNorm { const float* g; const float* b; bf16_t* y; float* mean; float* rstd; };
+
+struct SsLayerP {
+  int B, L, Lm;                      // samples, rows per sample (<= 32), memory rows per sample (<= 16; decoder layers)
+  int ff, act, last, causal;
+  const bf16_t* wpk; int nchunks;    // packed weight stream of this layer (stream order, see vct_ss_pack)
+  const bf16_t* x;                   // [B*L, 512] layer input
+  const bf16_t* mem;                 // [B*Lm, 512] encoder memory (decoder layers)
+  // self-attention block
+  const float* b_qkv; const float* b_o;
+  bf16_t* qkv; bf16_t* o; bf16_t* a;
+  SsNorm n1;
+  // cross-attention block
+  const float* b_cq; const float* b_ckv; const float* b_co;
+  bf16_t* cq; bf16_t* ckv; bf16_t* co; bf16_t* ca;
+  SsNorm n2;
+  // feed-forward block
+  const float* b1; const float* b2;
+  bf16_t* hpre; bf16_t* h; bf16_t* f;
+  SsNorm n3;
+  SsNorm nf;                         // stack-final norm (last != 0)
+  // masks of the self-attention (as vct_attn_desc)
+  const uint8_t* key_pad; int key_pad_shift;
+  const int64_t* key_ids; long key_ids_bs; long pad_id;
+  // dropout
+  const uint32_t* seed; float p_drop;
+  uint32_t site_sa, site_n1, site_ca, site_n2, site_ff, site_n3;
+};
+
+// ---- weight stream: this lane's view of the layer's packed weights ------------------------------------------------------------------
+// chunk c of the stream = elements [c*32768, (c+1)*32768): wave w's 8 fragments (column tile t, k-step s) at w*4096 + (t*2+s)*512,
+// lane l's 8 bf16 at + l*8.  Loads are UNCONDITIONAL (the pointer stops at the last chunk): straight-line code, exact vmcnt waits.
+struct WStream {
+  const bf16_t* p;        // next chunk to fetch (this lane)
+  const bf16_t* last;     // last chunk of the layer (this lane)
+};
+__device__ __forceinline__ void ws_fetch(WStream& ws, bf16x8 (&dst)[4][2]) {
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) dst[t][s] = *reinterpret_cast<const bf16x8*>(ws.p + (t * 2 + s) * 512);
+  ws.p = (ws.p + SS_CHUNK <= ws.last) ? ws.p + SS_CHUNK : ws.last;
+}
+
+// acc[m][t] += W_chunk-fragments x A-fragments for `nch` (even) chunks; A = LDS panel, this lane's pointer `a` already at
+// (row li, k-group lg*8), row-tile stride 16*astr, chunk kc0 first.  On entry buffer b0 holds the first chunk (in flight); on
+// exit b0 holds the first chunk of whatever comes next in the stream.
+template <int MT>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc0, const int nch, WStream& ws,
+                                          bf16x8 (&b0)[4][2], bf16x8 (&b1)[4][2]) {
+  auto step = [&](bf16x8 (&b)[4][2], const int kc) {
+    bf16x8 af[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int s = 0; s < 2; s++) af[m][s] = *reinterpret_cast<const bf16x8*>(a + m * 16 * astr + kc * 64 + s * 32);
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t][s], af[m][s], acc[m][t], 0, 0, 0);
+  };
+  for (int c = 0; c < nch; c += 2) {
+    ws_fetch(ws, b1);
+    step(b0, kc0 + c);
+    ws_fetch(ws, b0);
+    step(b1, kc0 + c + 1);
+  }
+}
+
+template <int MT> __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][4]) {
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[m][t] = f32x4{0, 0, 0, 0};
+}
+
+__device__ __forceinline__ void load_bias4(float4 (&bv)[4], const float* bias, const int col0, const int lg) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const float4*>(bias + col0 + t * 16 + lg * 4);
+}
+
+struct alignas(8) BV4 { bf16_t e[4]; };
+struct alignas(16) BV8s { bf16_t e[8]; };
+
+// rows [0, rows) x cols [0, ncols) of an LDS panel -> global [row0 + r][col0 ..], 16 bytes per thread and step
+__device__ __forceinline__ void panel_to_global(const bf16_t* panel, const int pstr, const int rows, const int ncols, bf16_t* g, const long ld,
+                                                const long row0, const int col0, const int tid) {
+  const int vpr = ncols >> 3, total = rows * vpr;
+  for (int v = tid; v < total; v += SS_NT) {
+    const int r = v / vpr, c = (v - r * vpr) * 8;
+    *reinterpret_cast<BV8s*>(g + (row0 + r) * ld + col0 + c) = *reinterpret_cast<const BV8s*>(panel + r * pstr + c);
+  }
+}
+// global rows -> panel (rows >= L zero-filled up to `alloc`)
+__device__ __forceinline__ void global_to_panel(bf16_t* panel, const int pstr, const int L, const int alloc, const bf16_t* g, const long ld,
+                                                const long row0, const int tid) {
+  constexpr int vpr = SS_D / 8;
+  for (int v = tid; v < alloc * vpr; v += SS_NT) {
+    const int r = v / vpr, c = (v - r * vpr) * 8;
+    BV8s val;
+    if (r < L) val = *reinterpret_cast<const BV8s*>(g + (row0 + r) * ld + c);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) val.e[j] = 0;
+    }
+    *reinterpret_cast<BV8s*>(panel + r * pstr + c) = val;
+  }
+}
+
+// plain epilogue: panel[row][pcol0 + ...] = bf16(acc + bias)
+template <int MT>
+__device__ __forceinline__ void epi_store(const f32x4 (&acc)[MT][4], const float4 (&bv)[4], bf16_t* panel, const int pstr, const int pcol0,
+                                          const int li, const int lg) {
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      BV4 o;
+      o.e[0] = f2bf(acc[m][t][0] + bv[t].x); o.e[1] = f2bf(acc[m][t][1] + bv[t].y);
+      o.e[2] = f2bf(acc[m][t][2] + bv[t].z); o.e[3] = f2bf(acc[m][t][3] + bv[t].w);
+      *reinterpret_cast<BV4*>(panel + (m * 16 + li) * pstr + pcol0 + t * 16 + lg * 4) = o;
+    }
+}
+
+// residual + dropout + LayerNorm (+ second LayerNorm) epilogue of out_proj / linear2 (what vct_add_ln_fwd / vct_add_ln_ln_fwd compute):
+//   a = bf16(acc + bias) -> panel AP;  s = a * dropmask + res;  y = LN(s) -> panel YP;  [y2 = LN2(bf16 y) -> panel Y2P]
+// res: 4 bf16 per (m, t) in registers.  Row statistics: this wave's 64 columns -> 4-lane-group shuffle -> LDS partials of the 8 waves.
+template <int MT>
+__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4], const BV4 (&res)[MT][4], const SsNorm& n, const SsNorm* n2,
+                                       const Dropout& dr, const long grow0, const int L, bf16_t* AP, bf16_t* YP, bf16_t* Y2P, float* red,
+                                       const int wave, const int li, const int lg) {
+  const int colw = wave * 64 + lg * 4;
+  float4 gm[4], bt[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    gm[t] = *reinterpret_cast<const float4*>(n.g + colw + t * 16);
+    bt[t] = *reinterpret_cast<const float4*>(n.b + colw + t * 16);
+  }
+  float part[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    part[m] = 0.0f;
+    const uint32_t grow = (uint32_t)(grow0 + m * 16 + li);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float bb[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+      float dm[4];
+      drop_mults<4>(dr, grow * (uint32_t)SS_D + (uint32_t)(colw + t * 16), dm);
+      BV4 av;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        av.e[r] = f2bf(acc[m][t][r] + bb[r]);          // the saved activation is the bf16 value, and the norm is built on it
+        const float s = bf2f(av.e[r]) * dm[r] + bf2f(res[m][t].e[r]);
+        acc[m][t][r] = s;
+        part[m] += s;
+      }
+      *reinterpret_cast<BV4*>(AP + (m * 16 + li) * SS_PSTR + colw + t * 16) = av;
+    }
+    part[m] = red4_sum(part[m]);
+  }
+  float* red0 = red;                  // [8][32]
+  float* red1 = red + SS_NW * 32;
+  auto stats = [&](float (&mean)[MT], float (&rstd)[MT]) {
+    if (lg == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; m++) red0[wave * 32 + m * 16 + li] = part[m];
+    }
+    __syncthreads();
+    float sq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int w = 0; w < SS_NW; w++) s += red0[w * 32 + m * 16 + li];
+      mean[m] = s * (1.0f / (float)SS_D);
+      sq[m] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float c = acc[m][t][r] - mean[m]; sq[m] += c * c; }
+      sq[m] = red4_sum(sq[m]);
+    }
+    if (lg == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; m++) red1[wave * 32 + m * 16 + li] = sq[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < SS_NW; w++) v += red1[w * 32 + m * 16 + li];
+      rstd[m] = 1.0f / sqrtf(v * (1.0f / (float)SS_D) + 1e-5f);
+    }
+  };
+  float mean[MT], rstd[MT];
+  stats(mean, rstd);
+  if (wave == 0 && lg == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+      if (m * 16 + li < L) { n.mean[grow0 + m * 16 + li] = mean[m]; n.rstd[grow0 + m * 16 + li] = rstd[m]; }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    part[m] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float gg[4] = {gm[t].x, gm[t].y, gm[t].z, gm[t].w}, be[4] = {bt[t].x, bt[t].y, bt[t].z, bt[t].w};
+      BV4 yv;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        yv.e[r] = f2bf((acc[m][t][r] - mean[m]) * rstd[m] * gg[r] + be[r]);
+        acc[m][t][r] = bf2f(yv.e[r]);                  // a second norm reads the rows as STORED
+        part[m] += acc[m][t][r];
+      }
+      *reinterpret_cast<BV4*>(YP + (m * 16 + li) * SS_PSTR + colw + t * 16) = yv;
+    }
+    part[m] = red4_sum(part[m]);
+  }
+  if (n2 != nullptr) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      gm[t] = *reinterpret_cast<const float4*>(n2->g + colw + t * 16);
+      bt[t] = *reinterpret_cast<const float4*>(n2->b + colw + t * 16);
+    }
+    stats(mean, rstd);
+    if (wave == 0 && lg == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+        if (m * 16 + li < L) { n2->mean[grow0 + m * 16 + li] = mean[m]; n2->rstd[grow0 + m * 16 + li] = rstd[m]; }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float gg[4] = {gm[t].x, gm[t].y, gm[t].z, gm[t].w}, be[4] = {bt[t].x, bt[t].y, bt[t].z, bt[t].w};
+        BV4 yv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) yv.e[r] = f2bf((acc[m][t][r] - mean[m]) * rstd[m] * gg[r] + be[r]);
+        *reinterpret_cast<BV4*>(Y2P + (m * 16 + li) * SS_PSTR + colw + t * 16) = yv;
+      }
+  }
+}
+
+// ---- attention of ONE head by ONE wave, operands in LDS panels (the arithmetic and the dropout stream of attn_fwd_wave) ------------
+// Qp / Kp / Vp point at this head's 64 columns; rows >= Lq / Lk of the panels hold finite values.  O^T tiles -> OP[row][h*64 + ...].
+__device__ __forceinline__ bf16x8 ss_frag_rowk(const bf16_t* p, const int str, const int row_base, const int ks, const int lane) {
+  return *reinterpret_cast<const bf16x8*>(p + (row_base + (lane & 15)) * str + ks * 32 + (lane >> 4) * 8);
+}
+__device__ __forceinline__ bf16x8 ss_frag_colk(const bf16_t* p, const int str, const int r0, const int r1, const int col_base, const int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const s16x4 lo = lds_tr16(p + (r0 + g * 4 + (i >> 2)) * str + col_base + (i & 3) * 4);
+  const s16x4 hi = lds_tr16(p + (r1 + g * 4 + (i >> 2)) * str + col_base + (i & 3) * 4);
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void ss_attn_wave(const bf16_t* Qp, const int strq, const bf16_t* Kp, const bf16_t* Vp, const int strkv, const int Lq,
+                                             const int Lk, const int causal, const unsigned long long padmask, const Dropout& dr, const int bh,
+                                             bf16_t* OPh, const int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int LQT = (Lq + 15) >> 4, LKT = (Lk + 15) >> 4;     // <= 2 each
+  const float scale = 0.125f;                                // 1 / sqrt(64)
+  for (int qt = 0; qt < LQT; qt++) {
+    f32x4 st[2];
+    const int qq = qt * 16 + i;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      st[t] = f32x4{0, 0, 0, 0};
+      if (t < LKT) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ss_frag_rowk(Kp, strkv, t * 16, ks, lane), ss_frag_rowk(Qp, strq, qt * 16, ks, lane),
+                                                          st[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int kk = t * 16 + g * 4 + r;
+        const bool masked = kk >= Lk || (causal && kk > qq) || ((padmask >> kk) & 1ull);
+        st[t][r] = (t < LKT && !masked) ? st[t][r] * scale : -INFINITY;
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) m = fmaxf(m, st[t][r]);
+    m = red4_max(m);
+    if (m == -INFINITY) m = 0.0f;
+    float l = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      if (t < LKT) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { st[t][r] = __expf(st[t][r] - m); l += st[t][r]; }
+      } else {
+        st[t] = f32x4{0, 0, 0, 0};
+      }
+    }
+    l = red4_sum(l);
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+      if (t < LKT) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int kk = t * 16 + g * 4 + r;
+          st[t][r] *= inv * drop_mult(dr, (uint32_t)((bh * Lq + qq) * Lk + kk));
+        }
+      }
+    const bf16x8 pa = pack_p(st[0], st[1]);
+    const int r1 = LKT > 1 ? 16 : 0;                         // one key tile: the second half of P is zero, re-read tile 0 (finite)
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+      f32x4 ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ss_frag_colk(Vp, strkv, 0, r1, dt * 16, lane), pa, f32x4{0, 0, 0, 0}, 0, 0, 0);
+      BV4 o;
+#pragma unroll
+      for (int r = 0; r < 4; r++) o.e[r] = f2bf(ot[r]);
+      *reinterpret_cast<BV4*>(OPh + (qt * 16 + i) * SS_PSTR + dt * 16 + g * 4) = o;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long ss_padmask(const SsLayerP& p, const int b, const int lane) {
+  if (p.key_ids != nullptr) {
+    const long id = p.key_ids[(long)b * p.key_ids_bs + min(lane, p.L - 1)];
+    return __ballot(lane < p.L && id == p.pad_id);
+  }
+  if (p.key_pad == nullptr) return 0ull;
+  const int w = p.L - p.key_pad_shift;
+  const int j = min(max(lane - p.key_pad_shift, 0), w - 1);
+  const uint8_t v = p.key_pad[(long)b * w + j];
+  return __ballot(lane >= p.key_pad_shift && lane < p.L && v != 0);
+}
+
+template <bool CROSS>
+__global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x, L = p.L;
+  const long grow0 = (long)b * L;
+  bf16_t* R0 = reinterpret_cast<bf16_t*>(smem + SS_R0);
+  bf16_t* R1A = reinterpret_cast<bf16_t*>(smem + SS_R1A);
+  bf16_t* R1B = reinterpret_cast<bf16_t*>(smem + SS_R1B);
+  bf16_t* R1C = reinterpret_cast<bf16_t*>(smem + SS_R1C);
+  bf16_t* RMp = reinterpret_cast<bf16_t*>(smem + SS_RM);
+  float* red = reinterpret_cast<float*>(smem + SS_RED);
+
+  WStream ws;
+  ws.p = p.wpk + (long)wave * 4096 + lane * 8;
+  ws.last = ws.p + (long)(p.nchunks - 1) * SS_CHUNK;
+  bf16x8 b0[4][2], b1[4][2];
+  ws_fetch(ws, b0);                                        // the stream starts before the first activation byte is here
+
+  global_to_panel(R0, SS_PSTR, L, 32, p.x, SS_D, grow0, tid);
+  if constexpr (CROSS) global_to_panel(RMp, SS_PSTR, p.Lm, 16, p.mem, SS_D, (long)b * p.Lm, tid);
+  const unsigned long long padmask = ss_padmask(p, b, lane);
+  __syncthreads();
+
+  const int aoff = li * SS_PSTR + lg * 8;                  // this lane's A-fragment origin inside a [32][SS_PSTR] panel
+  f32x4 acc[2][4];
+  float4 bv[4];
+
+  // ---- self-attention block ----------------------------------------------------------------------------------------------------------
+  for (int nb = 0; nb < 3; nb++) {                         // q | k | v = x W_in^T + b_in  -> panel [32][1544] in R1A..R1C
+    load_bias4(bv, p.b_qkv, nb * 512 + wave * 64, lg);
+    acc_zero<2>(acc);
+    wave_gemm<2>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+    epi_store<2>(acc, bv, R1A, SS_QSTR, nb * 512 + wave * 64, li, lg);
+  }
+  // residual rows of the out_proj epilogue: from HBM (the x panel is about to become the attention output panel)
+  BV4 res[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const long r = grow0 + min(m * 16 + li, L - 1);
+      res[m][t] = *reinterpret_cast<const BV4*>(p.x + r * SS_D + wave * 64 + t * 16 + lg * 4);
+    }
+  __syncthreads();
+  panel_to_global(R1A, SS_QSTR, L, 3 * SS_D, p.qkv, 3 * SS_D, grow0, 0, tid);
+  {
+    const Dropout dr = make_dropout(p.seed, p.site_sa, p.p_drop);
+    ss_attn_wave(R1A + wave * 64, SS_QSTR, R1A + SS_D + wave * 64, R1A + 2 * SS_D + wave * 64, SS_QSTR, L, L, p.causal, padmask, dr,
+                 b * SS_H + wave, R0 + wave * 64, lane);
+  }
+  __syncthreads();
+  panel_to_global(R0, SS_PSTR, L, SS_D, p.o, SS_D, grow0, 0, tid);
+  {                                                        // a = o W_o^T + b_o;  x1 = LN1(x + drop(a))
+    load_bias4(bv, p.b_o, wave * 64, lg);
+    acc_zero<2>(acc);
+    wave_gemm<2>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+    const Dropout dr = make_dropout(p.seed, p.site_n1, p.p_drop);
+    epi_ln<2>(acc, bv, res, p.n1, nullptr, dr, grow0, L, R1A, R1B, nullptr, red, wave, li, lg);
+  }
+  __syncthreads();
+  panel_to_global(R1A, SS_PSTR, L, SS_D, p.a, SS_D, grow0, 0, tid);
+  panel_to_global(R1B, SS_PSTR, L, SS_D, p.n1.y, SS_D, grow0, 0, tid);
+
+  // panels of the feed-forward phase (see the slot plan in DESIGN.md): input rows, pre-activation, activation, f, y, y2
+  bf16_t* FIN = CROSS ? R0 : R1B;
+  bf16_t* HPRE = CROSS ? R1A : R1C;
+  bf16_t* HP = CROSS ? R1B : R0;
+  bf16_t* FP = CROSS ? R1C : R1A;
+  bf16_t* YP = CROSS ? R1A : R1C;
+  bf16_t* Y2P = CROSS ? R1B : R0;
+
+  if constexpr (CROSS) {
+    // ---- cross-attention block -------------------------------------------------------------------------------------------------------
+    const int Lm = p.Lm;
+    load_bias4(bv, p.b_cq, wave * 64, lg);                 // q = x1 W_q^T + b_q -> R1C
+    acc_zero<2>(acc);
+    wave_gemm<2>(acc, R1B + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+    epi_store<2>(acc, bv, R1C, SS_PSTR, wave * 64, li, lg);
+    for (int nb = 0; nb < 2; nb++) {                       // k | v = mem W_kv^T + b_kv -> panel [16][1032] in R0
+      f32x4 acm[1][4];
+      load_bias4(bv, p.b_ckv, nb * 512 + wave * 64, lg);
+      acc_zero<1>(acm);
+      wave_gemm<1>(acm, RMp + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      epi_store<1>(acm, bv, R0, SS_KVSTR, nb * 512 + wave * 64, li, lg);
+    }
+    __syncthreads();
+    panel_to_global(R1C, SS_PSTR, L, SS_D, p.cq, SS_D, grow0, 0, tid);
+    panel_to_global(R0, SS_KVSTR, Lm, 2 * SS_D, p.ckv, 2 * SS_D, (long)b * Lm, 0, tid);
+    {
+      const Dropout dr = make_dropout(p.seed, p.site_ca, p.p_drop);
+      // rows >= Lm of the 16-row k | v panel: computed from zero memory rows = the bias, finite
+      ss_attn_wave(R1C + wave * 64, SS_PSTR, R0 + wave * 64, R0 + SS_D + wave * 64, SS_KVSTR, L, Lm, 0, 0ull, dr, b * SS_H + wave,
+                   R1A + wave * 64, lane);
+    }
+    __syncthreads();
+    panel_to_global(R1A, SS_PSTR, L, SS_D, p.co, SS_D, grow0, 0, tid);
+    {                                                      // a2 = o2 W_o^T + b_o;  x2 = LN2(x1 + drop(a2)); residual x1 still in R1B
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R1B + (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4);
+      load_bias4(bv, p.b_co, wave * 64, lg);
+      acc_zero<2>(acc);
+      wave_gemm<2>(acc, R1A + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      const Dropout dr = make_dropout(p.seed, p.site_n2, p.p_drop);
+      epi_ln<2>(acc, bv, res, p.n2, nullptr, dr, grow0, L, R1C, R0, nullptr, red, wave, li, lg);
+    }
+    __syncthreads();
+    panel_to_global(R1C, SS_PSTR, L, SS_D, p.ca, SS_D, grow0, 0, tid);
+    panel_to_global(R0, SS_PSTR, L, SS_D, p.n2.y, SS_D, grow0, 0, tid);
+  }
+
+  // ---- feed-forward block: ff / 512 chunks of (linear1 block -> GELU, dropout -> linear2 K slice) ------------------------------------
+  f32x4 facc[2][4];
+  acc_zero<2>(facc);
+  const Dropout drf = make_dropout(p.seed, p.site_ff, p.p_drop);
+  const int nj = p.ff >> 9;
+  for (int j = 0; j < nj; j++) {
+    load_bias4(bv, p.b1, j * 512 + wave * 64, lg);
+    acc_zero<2>(acc);
+    wave_gemm<2>(acc, FIN + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+    if (j > 0) __syncthreads();                            // the previous chunk's panels have been copied out / consumed by linear2
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const uint32_t grow = (uint32_t)(grow0 + m * 16 + li);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int col = j * 512 + wave * 64 + t * 16 + lg * 4;
+        float dm[4];
+        drop_mults<4>(drf, grow * (uint32_t)p.ff + (uint32_t)col, dm);
+        const vf2 x0 = {acc[m][t][0] + bv[t].x, acc[m][t][1] + bv[t].y}, x1 = {acc[m][t][2] + bv[t].z, acc[m][t][3] + bv[t].w};
+        BV4 pv, hv;
+        pv.e[0] = f2bf(x0[0]); pv.e[1] = f2bf(x0[1]); pv.e[2] = f2bf(x1[0]); pv.e[3] = f2bf(x1[1]);
+        const vf2 a0 = act_fast_f2(p.act, x0) * vf2{dm[0], dm[1]}, a1 = act_fast_f2(p.act, x1) * vf2{dm[2], dm[3]};
+        hv.e[0] = f2bf(a0[0]); hv.e[1] = f2bf(a0[1]); hv.e[2] = f2bf(a1[0]); hv.e[3] = f2bf(a1[1]);
+        const int off = (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4;
+        *reinterpret_cast<BV4*>(HPRE + off) = pv;
+        *reinterpret_cast<BV4*>(HP + off) = hv;
+      }
+    }
+    __syncthreads();
+    panel_to_global(HPRE, SS_PSTR, L, SS_D, p.hpre, p.ff, grow0, j * 512, tid);
+    panel_to_global(HP, SS_PSTR, L, SS_D, p.h, p.ff, grow0, j * 512, tid);
+    wave_gemm<2>(facc, HP + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+  }
+  {                                                        // f = h W_2^T + b_2;  y = LN(x_in + drop(f)) [; y2 = LN_final(y)]
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(FIN + (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4);
+    load_bias4(bv, p.b2, wave * 64, lg);
+    __syncthreads();                                       // the last chunk's copies and linear2 reads are done: HPRE / HP become y / y2
+    const Dropout dr = make_dropout(p.seed, p.site_n3, p.p_drop);
+    epi_ln<2>(facc, bv, res, p.n3, p.last ? &p.nf : nullptr, dr, grow0, L, FP, YP, Y2P, red, wave, li, lg);
+  }
+  __syncthreads();
+  panel_to_global(FP, SS_PSTR, L, SS_D, p.f, SS_D, grow0, 0, tid);
+  panel_to_global(YP, SS_PSTR, L, SS_D, p.n3.y, SS_D, grow0, 0, tid);
+  if (p.last) panel_to_global(Y2P, SS_PSTR, L, SS_D, p.nf.y, SS_D, grow0, 0, tid);
+}
+
+// ---- stream-order packing of weight blocks ---------------------------------------------------------------------------------------------
+constexpr int SS_PACK_MAX = 48;
+struct SsPackSeg { const bf16_t* w; long ldw; int nchunks; int dst_chunk; };
+struct SsPackP { SsPackSeg seg[SS_PACK_MAX]; int nseg; bf16_t* dst; };
+
+// one thread = one 16-byte vector of the stream: (chunk, wave, tile t, k-step s, lane) <- W[w*64 + t*16 + (lane & 15)][chunk*64 + s*32 + (lane >> 4)*8 ..]
+__global__ __launch_bounds__(256) void ss_pack_kernel(const SsPackP p) {
+  const int sg = blockIdx.y;
+  if (sg >= p.nseg) return;
+  const SsPackSeg s = p.seg[sg];
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;     // vector index inside the segment
+  if (v >= (long)s.nchunks * (SS_CHUNK / 8)) return;
+  const int lane = (int)(v & 63), frag = (int)((v >> 6) & 7), w = (int)((v >> 9) & 7);
+  const long c = v >> 12;
+  const int t = frag >> 1, ks = frag & 1;
+  const int n = w * 64 + t * 16 + (lane & 15);
+  const long k = c * 64 + ks * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<BV8s*>(p.dst + ((long)s.dst_chunk + c) * SS_CHUNK + (v & 4095) * 8) = *reinterpret_cast<const BV8s*>(s.w + (long)n * s.ldw + k);
+}
+
+}  // namespace vct
+using namespace vct;
+
+extern "C" int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm) {
+  if (dtype != VCT_BF16 || d != SS_D || H != SS_H) return 0;
+  if (ff < 512 || (ff % 512) != 0) return 0;
+  if (L < 1 || L > 32) return 0;
+  if (Lm < 0 || Lm > 16) return 0;        // Lm = 0: encoder layer
+  return 1;
+}
+
+extern "C" int64_t vct_layer_ss_stream_chunks(int ff, int cross) {
+  // q|k|v 3 blocks + out_proj 1 [+ cross q 1 + cross k|v 2 + cross out_proj 1] + ff/512 x (linear1 block + linear2 K slice), 8 chunks each
+  return (int64_t)8 * (4 + (cross ? 4 : 0) + 2 * (ff / 512));
+}
+
+extern "C" int vct_ss_pack(const vct_ss_pack_seg* segs, int nseg, void* dst, void* stream) {
+  if (segs == nullptr || dst == nullptr || nseg < 1) return VCT_E_ARG;
+  if (((uintptr_t)dst & 15)) return VCT_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < nseg; base += SS_PACK_MAX) {
+    SsPackP p;
+    p.nseg = nseg - base < SS_PACK_MAX ? nseg - base : SS_PACK_MAX;
+    p.dst = reinterpret_cast<bf16_t*>(dst);
+    int maxch = 0;
+    for (int i = 0; i < p.nseg; i++) {
+      const vct_ss_pack_seg& s = segs[base + i];
+      if (s.w == nullptr || s.nchunks < 1 || s.dst_chunk < 0) return VCT_E_ARG;
+      if ((s.ldw % 8) || ((uintptr_t)s.w & 15)) return VCT_E_ALIGN;
+      p.seg[i].w = reinterpret_cast<const bf16_t*>(s.w); p.seg[i].ldw = s.ldw; p.seg[i].nchunks = s.nchunks; p.seg[i].dst_chunk = (int)s.dst_chunk;
+      maxch = s.nchunks > maxch ? s.nchunks : maxch;
+    }
+    for (int i = p.nseg; i < SS_PACK_MAX; i++) p.seg[i] = SsPackSeg{nullptr, 0, 0, 0};
+    const dim3 grid((unsigned)((long)maxch * (SS_CHUNK / 8) / 256), p.nseg);
+    vct::launch(ss_pack_kernel, grid, dim3(256), 0, st, p);
+    VCT_CHECK_LAUNCH();
+  }
+  return VCT_OK;
+}
+
+extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* q, void* stream) {
+  if (q == nullptr) return VCT_E_ARG;
+  const int cross = q->mem != nullptr;
+  if (!vct_layer_ss_supported(q->dtype, q->d, q->H, q->ff, q->L, cross ? q->Lm : 0) || q->B < 1) return VCT_E_SHAPE;
+  if (cross && q->Lm < 1) return VCT_E_SHAPE;
+  if (q->nchunks != vct_layer_ss_stream_chunks(q->ff, cross)) return VCT_E_SHAPE;
+  if (!q->wpk || !q->x || !q->b_qkv || !q->b_o || !q->qkv || !q->o || !q->a || !q->b1 || !q->b2 || !q->hpre || !q->h || !q->f) return VCT_E_ARG;
+  auto norm_ok = [](const vct_ss_norm& n) { return n.gamma && n.beta && n.y && n.mean && n.rstd; };
+  if (!norm_ok(q->n1) || !norm_ok(q->n3) || (q->last && !norm_ok(q->nf))) return VCT_E_ARG;
+  if (cross && (!q->b_cq || !q->b_ckv || !q->b_co || !q->cq || !q->ckv || !q->co || !q->ca || !norm_ok(q->n2))) return VCT_E_ARG;
+  if (q->key_pad_shift < 0 || (q->key_pad != nullptr && q->key_pad_shift >= q->L)) return VCT_E_SHAPE;
+  const uintptr_t al = (uintptr_t)q->wpk | (uintptr_t)q->x | (uintptr_t)q->mem | (uintptr_t)q->qkv | (uintptr_t)q->o | (uintptr_t)q->a |
+                       (uintptr_t)q->cq | (uintptr_t)q->ckv | (uintptr_t)q->co | (uintptr_t)q->ca | (uintptr_t)q->hpre | (uintptr_t)q->h |
+                       (uintptr_t)q->f | (uintptr_t)q->n1.y | (uintptr_t)q->n2.y | (uintptr_t)q->n3.y | (uintptr_t)q->nf.y |
+                       (uintptr_t)q->b_qkv | (uintptr_t)q->b_o | (uintptr_t)q->b_cq | (uintptr_t)q->b_ckv | (uintptr_t)q->b_co |
+                       (uintptr_t)q->b1 | (uintptr_t)q->b2;
+  if (al & 15) return VCT_E_ALIGN;
+  SsLayerP p;
+  p.B = q->B; p.L = q->L; p.Lm = cross ? q->Lm : 0; p.ff = q->ff; p.act = q->act; p.last = q->last; p.causal = q->causal;
+  p.wpk = reinterpret_cast<const bf16_t*>(q->wpk); p.nchunks = (int)q->nchunks;
+  p.x = reinterpret_cast<const bf16_t*>(q->x); p.mem = reinterpret_cast<const bf16_t*>(q->mem);
+  p.b_qkv = q->b_qkv; p.b_o = q->b_o;
+  p.qkv = reinterpret_cast<bf16_t*>(q->qkv); p.o = reinterpret_cast<bf16_t*>(q->o); p.a = reinterpret_cast<bf16_t*>(q->a);
+  auto cvt = [](const vct_ss_norm& n) { return SsNorm{n.gamma, n.beta, reinterpret_cast<bf16_t*>(n.y), n.mean, n.rstd}; };
+  p.n1 = cvt(q->n1); p.n2 = cvt(q->n2); p.n3 = cvt(q->n3); p.nf = cvt(q->nf);
+  p.b_cq = q->b_cq; p.b_ckv = q->b_ckv; p.b_co = q->b_co;
+  p.cq = reinterpret_cast<bf16_t*>(q->cq); p.ckv = reinterpret_cast<bf16_t*>(q->ckv); p.co = reinterpret_cast<bf16_t*>(q->co);
+  p.ca = reinterpret_cast<bf16_t*>(q->ca);
+  p.b1 = q->b1; p.b2 = q->b2;
+  p.hpre = reinterpret_cast<bf16_t*>(q->hpre); p.h = reinterpret_cast<bf16_t*>(q->h); p.f = reinterpret_cast<bf16_t*>(q->f);
+  p.key_pad = q->key_pad; p.key_pad_shift = q->key_pad_shift; p.key_ids = q->key_ids; p.key_ids_bs = q->key_ids_bs; p.pad_id = q->pad_id;
+  p.seed = q->seed; p.p_drop = q->p_drop;
+  p.site_sa = q->site_sa; p.site_n1 = q->site_n1; p.site_ca = q->site_ca; p.site_n2 = q->site_n2; p.site_ff = q->site_ff; p.site_n3 = q->site_n3;
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[cross]) {
+    hipError_t e = cross ? hipFuncSetAttribute((const void*)layer_ss_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS)
+                         : hipFuncSetAttribute((const void*)layer_ss_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set[cross] = true;
+  }
+  if (cross) vct::launch(layer_ss_fwd_kernel<true>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+  else vct::launch(layer_ss_fwd_kernel<false>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}

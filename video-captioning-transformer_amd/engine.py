@@ -75,6 +75,9 @@ class ParamSet:
         # transposed copies of individual weight matrices in the compute dtype (name -> (tensor [cols, ld], start, end)): kept in
         # step with the shadow by refresh_shadow / cast_range / FusedAdam.step_range (refresh_transposed)
         self.transposed = {}
+        # STREAM-ORDER packed copies of whole layers (key -> [tensor, start, end, blocks, nchunks, dirty]): the operand of the
+        # sample-stationary layer kernels (ops.layer_ss_fwd), kept in step with the shadow exactly like the eager transposed copies
+        self.packed = {}
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
         self.cast_ranges, start = [], 0
         for n in self.names:
@@ -141,6 +144,24 @@ class ParamSet:
             ent[4] = self.version
         return ent[0]
 
+    def want_packed(self, key: str, names, blocks_fn):
+        """(stream, nchunks): the weights `names` of one Transformer layer packed in the order the sample-stationary layer kernel
+        consumes them (include/vct_hip.h, vct_ss_pack), created on first use and rewritten whenever the shadow of that layer is
+        (refresh_transposed: behind the optimizer's pass, inside the recorded step).  blocks_fn() -> [(2-D shadow view, nchunks,
+        first chunk)]."""
+        ent = self.packed.get(key)
+        if ent is None:
+            blocks = blocks_fn()
+            total = max(dc + nch for _w, nch, dc in blocks)
+            t = torch.empty(total * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
+            a = min(self.offsets[n] for n in names)
+            b = max(self.offsets[n] + self.params[n].numel() for n in names)
+            ent = self.packed[key] = [t, a, b, blocks, total, True]
+        if ent[5]:
+            ops.ss_pack(ent[3], ent[0])
+            ent[5] = False
+        return ent[0], ent[4]
+
     def refresh_lazy_transposed(self):
         """Bring every on-demand transposed copy up to date (decode entry points call this before replaying captured steps,
         which bake the copies' addresses but cannot notice that the weights moved on)."""
@@ -155,6 +176,13 @@ class ParamSet:
         for name, ent in self.transposed.items():
             if ent[3] and name not in skip and a <= ent[1] and ent[2] <= b:
                 ops.transpose(self.c[name], ent[0])
+        for ent in self.packed.values():
+            if ent[2] > a and ent[1] < b:                     # the rewritten range touches this layer
+                if a <= ent[1] and ent[2] <= b:
+                    ops.ss_pack(ent[3], ent[0])
+                    ent[5] = False
+                else:                                         # partly rewritten (no schedule does this): re-pack at the next use
+                    ent[5] = True
 
     def eager_transposed_in(self, a: int, b: int):
         """[(name, tensor, start, end)] of the eager transposed copies whose weight lies inside flat elements [a, b)."""
@@ -472,6 +500,73 @@ class _StackBase:
         ops.ln_param_finalize_batched(tab, len(self._ln_pending), self.cfg["d"])
         self._ln_pending = []
 
+    # ---- ONE launch per layer: the sample-stationary forward (csrc/vct_layer_ss.hip) ---------------------------------------
+    # A/B switch.  bf16, d = 512 / 8 heads, rows per sample <= 32, memory rows <= 16: every layer of the stack is one launch in
+    # which a workgroup keeps its sample in LDS and streams the layer's weights (a stream-order packed second shadow) from L2.
+    # It saves the tensors and draws the dropout streams of the unfused kernels: the backward schedule is unchanged behind it.
+    fuse_layers = os.environ.get("VCT_FUSE_LAYERS", "1") != "0"
+
+    def _ss_ok(self, Lr: int, Lm: int) -> bool:
+        c = self.cfg
+        return (self.fuse_layers and self.dev.type == "cuda" and c["activation"] in ("gelu", "relu")
+                and ops.layer_ss_supported(self.dt, c["d"], c["nhead"], c["ff"], Lr, Lm))
+
+    def _ss_stream(self, lp: str, cross: bool):
+        """The packed weight stream of layer `lp` (blocks in the kernel's consumption order)."""
+        P, ff = self.pre + lp, self.cfg["ff"]
+        names = [P + "self_attn.in_proj_weight", P + "self_attn.out_proj.weight", P + "linear1.weight", P + "linear2.weight"]
+        if cross:
+            names += [P + "multihead_attn.in_proj_weight", P + "multihead_attn.out_proj.weight"]
+
+        def blocks():
+            c, out, at = self.ps.c, [], 0
+            mats = [(c[P + "self_attn.in_proj_weight"], 3), (c[P + "self_attn.out_proj.weight"], 1)]
+            if cross:
+                mats += [(c[P + "multihead_attn.in_proj_weight"], 3), (c[P + "multihead_attn.out_proj.weight"], 1)]
+            for w, nb in mats:
+                for i in range(nb):
+                    out.append((w[512 * i:512 * (i + 1)], 8, at)); at += 8
+            w1, w2 = c[P + "linear1.weight"], c[P + "linear2.weight"]
+            for j in range(ff // 512):
+                out.append((w1[512 * j:512 * (j + 1)], 8, at)); at += 8
+                out.append((w2[:, 512 * j:512 * (j + 1)], 8, at)); at += 8
+            return out
+        return self.ps.want_packed(P, names, blocks)
+
+    def _layer_ss(self, b, lp, tag, x, Bn, Lr, site, *, ln_tag, ln_name, mem=None, Lm=0, causal=False, kpm=None, final=None):
+        """Layer `lp` on input x [Bn*Lr, d] in one launch.  ln_tag / ln_name: buffer tag and parameter name of the layer's closing
+        norm ('n2.' / 'norm2.' encoder, 'n3.' / 'norm3.' decoder); final = parameter prefix of the stack-final norm (last layer).
+        Returns (layer output, final-norm output or None)."""
+        d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
+        M, cross = Bn * Lr, mem is not None
+        f32 = torch.float32
+        wpk, nch = self._ss_stream(lp, cross)
+
+        def norm(t, name):
+            return (self.F(name + "weight"), self.F(name + "bias"), b.get(t + "y", (M, d), self.dt), b.get(t + "mean", (M,), f32),
+                    b.get(t + "rstd", (M,), f32))
+        sa, st = lp + "self_attn.", tag + "sa."
+        bias = {"qkv": self.F(sa + "in_proj_bias"), "o": self.F(sa + "out_proj.bias"), "l1": self.F(lp + "linear1.bias"),
+                "l2": self.F(lp + "linear2.bias")}
+        kw = {}
+        if cross:
+            ca, ct = lp + "multihead_attn.", tag + "ca."
+            bias.update(cq=self.F(ca + "in_proj_bias")[:d], ckv=self.F(ca + "in_proj_bias")[d:], co=self.F(ca + "out_proj.bias"))
+            kw = dict(cross=(b.get(ct + "q", (M, d), self.dt), b.get(ct + "kv", (Bn * Lm, 2 * d), self.dt), b.get(ct + "o", (M, d), self.dt),
+                             b.get(ct + "a", (M, d), self.dt)),
+                      n2=norm(tag + "n2.", lp + "norm2."), mem=mem, Lm=Lm)
+            sites = (site + 1, site + 2, site + 3, site + 4, site + 5, site + 6)
+        else:
+            sites = (site + 1, site + 2, 0, 0, site + 3, site + 4)
+        nl = norm(tag + ln_tag, lp + ln_name)
+        nf = norm("nf.", final) if final is not None else None
+        ops.layer_ss_fwd(B=Bn, Lr=Lr, x=x, wpk=wpk, nchunks=nch, ff=ff, act=self.cfg["activation"], H=H, bias=bias,
+                         sa=(b.get(st + "qkv", (M, 3 * d), self.dt), b.get(st + "o", (M, d), self.dt), b.get(st + "a", (M, d), self.dt)),
+                         n1=norm(tag + "n1.", lp + "norm1."),
+                         ffn=(b.get(tag + "ff.hpre", (M, ff), self.dt), b.get(tag + "ff.h", (M, ff), self.dt), b.get(tag + "ff.f", (M, d), self.dt)),
+                         n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites, **kw)
+        return nl[2], (nf[2] if nf is not None else None)
+
     def _ffn_fwd(self, b, tag, lp, x, site):
         M, d = x.shape
         ff = self.cfg["ff"]
@@ -538,6 +633,15 @@ class EncoderEngine(_StackBase):
             mk = mask if mask.is_contiguous() else mask.contiguous()
             kpm = (mk.view(torch.uint8) if mk.dtype == torch.bool else mk, 1)
         b.t["kpm_used"] = kpm
+        if self._ss_ok(Te, 0):          # one launch per layer (+ the stack-final norm inside the last one)
+            mem = None
+            for l in range(L):
+                lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
+                b.t[tag + "x"] = x
+                x, mem = self._layer_ss(b, lp, tag, x, B, Te, site, ln_tag="n2.", ln_name="norm2.", kpm=kpm,
+                                        final="transformer_encoder.norm." if l == L - 1 else None)
+            b.t["x_last"] = x
+            return mem
         for l in range(L):
             lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
             b.t[tag + "x"] = x
@@ -587,6 +691,12 @@ class DecoderEngine(_StackBase):
         self.pos = pos_buffer  # [5000, d] fp32 buffer
         self.V = cfg["vocab"]
         self.Vp = (self.V + 31) // 32 * 32
+        # set per ENGINE by trainer.CaptionTrainer (single GPU, fused optimizer): nothing but this engine's backward schedule writes
+        # the flat gradient buffer, so the token-embedding gradient only re-zeroes the rows it wrote in the previous step
+        self.exclusive_grads = False
+
+    def _ws_grew(self):
+        self.ps.ctx.generation += 1      # recordings that baked the outgrown id workspace are dropped by their owners
 
     def _embed(self, b, ids, Sd, M):
         return ops.embed_fwd(ids, Sd, self.F("tgt_to_emb.weight"), self.pos, b.get("x0", (M, self.cfg["d"]), self.dt),
@@ -606,6 +716,9 @@ class DecoderEngine(_StackBase):
         pad, S = self.cfg["pad_id"], ids.shape[1]
         Sd, M = S - 1, Bn * (S - 1)
         self.p_drop = self.cfg["dropout"] if training else 0.0
+        if self._ss_ok(Sd, Te):         # one launch per layer fills every CU: nothing to run beside the encoder
+            self._prefix = None
+            return
         b = self.buf((Bn, Te, S))
         kpm = ("ids", ids, pad)
 
@@ -620,6 +733,16 @@ class DecoderEngine(_StackBase):
         d, L = self.cfg["d"], self.cfg["layers"]
         M = Bn * Sd
         prefix, self._prefix = self._prefix, None
+        if self._ss_ok(Sd, Te) and prefix is None:
+            x, y = self._embed(b, ids, Sd, M), None
+            self._kv_prefetched, self._kv_inplace = None, set()
+            for l in range(L):
+                lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
+                b.t[tag + "x"] = x
+                x, y = self._layer_ss(b, lp, tag, x, Bn, Sd, site, ln_tag="n3.", ln_name="norm3.", mem=mem, Lm=Te, causal=True, kpm=kpm,
+                                      final="decoder.norm." if l == L - 1 else None)
+            b.t["x_last"] = x
+            return y
         if prefix is not None and prefix[0] is b:        # embedding + bottom self-attention already ran beside the encoder
             x, x1_0 = prefix[1], prefix[2]
             # the main stream has nothing else to do until the bottom cross-attention: its K/V projection runs here, in
@@ -763,7 +886,7 @@ class DecoderEngine(_StackBase):
                     bucket_ready("dec_layer", l)
                 self.flush_ln_grads(b)
                 ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE),
-                              exclusive=self.exclusive_grads and bucket_ready is None)
+                              exclusive=self.exclusive_grads and bucket_ready is None, on_grow=self._ws_grew)
                 if bucket_ready is not None:
                     bucket_ready("embedding")
                 if defer_gen_dw:
@@ -778,7 +901,7 @@ class DecoderEngine(_StackBase):
                 self.bucket_on_side(bucket_ready, "dec_layer", l)
         self.flush_ln_grads(b)
         ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE),
-                      exclusive=self.exclusive_grads and bucket_ready is None)
+                      exclusive=self.exclusive_grads and bucket_ready is None, on_grow=self._ws_grew)
         if bucket_ready is not None:
             bucket_ready("embedding")
         if join:
@@ -924,7 +1047,8 @@ def _decoder_decode_step_small(self, st: DecodeState, t: int, end_id: int):
 
 
 def _decoder_block_decode_ok(self, st: DecodeState) -> bool:
-    """The batch-1 step with one launch per layer BLOCK (ops.decode_block): bf16, head_dim 64, d = 512 / 1024, <= 64 positions."""
+    """The batch-1 step with one launch per layer BLOCK (ops.decode_block): bf16, d = 512 with head_dim 64, ff <= 2048, <= 64 positions
+    (vct_decode_block_supported is the authority: anything else falls through to the gemv / skinny / batched steps)."""
     d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
     return (self.block_decode and st.B == 1 and self.dev.type == "cuda" and st.Lmax <= 64 and st.Te <= 64
             and ops.decode_block_supported(self.dt, d, H, ff, min(st.Lmax, 64)))
@@ -1046,9 +1170,6 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
 DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "1") != "0"
 DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
-# set by trainer.CaptionTrainer (single GPU, fused optimizer): nothing but the backward schedule writes the flat gradient buffer,
-# so the token-embedding gradient only re-zeroes the rows it wrote in the previous step (ops.embed_bwd)
-DecoderEngine.exclusive_grads = False
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 

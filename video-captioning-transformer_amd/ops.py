@@ -191,6 +191,77 @@ def attn_block_fwd(q, k, v, o, B, H, Lq, Lk, w_out, b_out, res, gamma, beta, a_o
     return y
 
 
+# ---- sample-stationary layer forward (csrc/vct_layer_ss.hip) ---------------------------------------------------------------------
+_ss_ok = {}
+SS_CHUNK = 32768          # bf16 elements per 64-KiB chunk of a packed weight stream
+
+
+def layer_ss_supported(dtype, d: int, H: int, ff: int, L_: int, Lm: int) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    key = (d, H, ff, L_, Lm)
+    r = _ss_ok.get(key)
+    if r is None:
+        r = _ss_ok[key] = bool(L.load().vct_layer_ss_supported(L.BF16, d, H, ff, L_, Lm))
+    return r
+
+
+def layer_ss_stream_chunks(ff: int, cross: bool) -> int:
+    return int(L.load().vct_layer_ss_stream_chunks(int(ff), int(cross)))
+
+
+def ss_pack(blocks, dst: torch.Tensor):
+    """blocks: [(w2d bf16 view whose rows 0..511 x columns 0..64*nchunks-1 form the block, nchunks, dst_chunk)] -> the packed stream
+    `dst` (bf16, stream order: include/vct_hip.h, vct_ss_pack).  One launch per 48 blocks."""
+    n = len(blocks)
+    segs = (L.SsPackSeg * n)()
+    for i, (w, nch, dc) in enumerate(blocks):
+        assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and w.shape[0] >= 512 and w.shape[1] >= 64 * nch
+        segs[i].w, segs[i].ldw, segs[i].nchunks, segs[i].dst_chunk = w.data_ptr(), w.stride(0), int(nch), int(dc)
+    L.check(L.load().vct_ss_pack(segs, n, dst.data_ptr(), L.stream_ptr()), "vct_ss_pack")
+    return dst
+
+
+def layer_ss_fwd(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, cross=None, n2=None, nf=None, mem=None, Lm=0,
+                 causal=False, key_pad=None, seed=None, p_drop=0.0, sites=(0, 0, 0, 0, 0, 0)):
+    """One whole Transformer layer (include/vct_hip.h, vct_layer_ss_fwd).  bias = dict(qkv, o, [cq, ckv, co], l1, l2) fp32 vectors;
+    sa = (qkv, o, a); cross = (q, kv, o, a); ffn = (hpre, h, f); nX = (gamma, beta, y, mean, rstd); sites = dropout sites
+    (self-attention probabilities, norm1, cross-attention probabilities, norm2, feed-forward, norm3)."""
+    q = L.LayerSsDesc()
+    q.dtype, q.B, q.L, q.Lm, q.d, q.H, q.ff, q.act = L.BF16, int(B), int(Lr), int(Lm), x.shape[1], int(H), int(ff), L.ACT[act]
+    q.last, q.causal = int(nf is not None), int(causal)
+    q.wpk, q.nchunks, q.x, q.mem = wpk.data_ptr(), int(nchunks), x.data_ptr(), L.ptr(mem)
+
+    def norm(dst, t):
+        dst.gamma, dst.beta, dst.y, dst.mean, dst.rstd = (z.data_ptr() for z in t)
+    q.b_qkv, q.b_o = bias["qkv"].data_ptr(), bias["o"].data_ptr()
+    q.qkv, q.o, q.a = (t.data_ptr() for t in sa)
+    norm(q.n1, n1)
+    if cross is not None:
+        q.b_cq, q.b_ckv, q.b_co = bias["cq"].data_ptr(), bias["ckv"].data_ptr(), bias["co"].data_ptr()
+        q.cq, q.ckv, q.co, q.ca = (t.data_ptr() for t in cross)
+        norm(q.n2, n2)
+    q.b1, q.b2 = bias["l1"].data_ptr(), bias["l2"].data_ptr()
+    q.hpre, q.h, q.f = (t.data_ptr() for t in ffn)
+    norm(q.n3, n3)
+    if nf is not None:
+        norm(q.nf, nf)
+    if isinstance(key_pad, tuple) and key_pad[0] == "ids":
+        _tag, ids, pad_id = key_pad
+        assert ids.dtype == torch.int64 and ids.stride(1) == 1 and ids.shape[1] >= Lr
+        q.key_ids, q.key_ids_bs, q.pad_id = ids.data_ptr(), ids.stride(0), int(pad_id)
+    elif isinstance(key_pad, tuple):
+        m, shift = key_pad
+        assert m.is_contiguous() and m.element_size() == 1 and tuple(m.shape) == (B, Lr - shift)
+        q.key_pad, q.key_pad_shift = m.data_ptr(), int(shift)
+    elif key_pad is not None:
+        q.key_pad = key_pad.data_ptr()
+    if seed is not None and p_drop > 0.0:
+        q.seed, q.p_drop = seed.data_ptr(), float(p_drop)
+    q.site_sa, q.site_n1, q.site_ca, q.site_n2, q.site_ff, q.site_n3 = (int(s) for s in sites)
+    L.check(L.load().vct_layer_ss_fwd(q, L.stream_ptr()), "vct_layer_ss_fwd")
+
+
 _ll_ok = {}
 
 
@@ -296,7 +367,7 @@ _embed_ws = {}
 _embed_ws_retired = []
 
 
-def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, exclusive: bool = False):
+def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, exclusive: bool = False, on_grow=None):
     """dtable fp32 [V, d] = deterministic scatter-add of the dx rows.  exclusive=True: the caller guarantees that nothing but
     this function writes `dtable` between calls (the single-GPU fast training path: gradients are overwritten every step, never
     accumulated or averaged in place) -- from the second exclusive call on, only the rows the previous call wrote are zeroed
@@ -316,6 +387,10 @@ def embed_bwd(ids, S, pad_id, dx, dtable, dropout: Drop = None, id_ws=None, excl
             # for 65536 positions up front (recordings bake its address); an outgrown one stays alive for the recordings that use it
             if ent is not None:
                 _embed_ws_retired.append(ent[0])
+                # recordings made against the old workspace carry incremental = 1 and ITS "previous ids": replayed after a step on
+                # the new workspace they would zero the wrong rows -> the owner drops them (engine: ctx.generation += 1)
+                if on_grow is not None:
+                    on_grow()
             ent = _embed_ws[key] = [torch.zeros(need, dtype=torch.int32, device=dx.device), None]
         id_ws = ent[0]
         incremental = exclusive and ent[1] == dtable.data_ptr()
