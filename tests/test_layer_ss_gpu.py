@@ -129,7 +129,10 @@ def test_fused_equals_unfused_schedule(dropout):
     for k in saved:
         # rows of padded FRAMES / tokens carry values nothing downstream reads identically in both schedules; statistics and
         # activations of all real rows must agree
-        tol = 3e-2 if (k.endswith("mean") or k.endswith("rstd")) else 2.5e-2
+        if k.endswith("mean"):          # row means of O(1) activations are ~1e-3: an absolute bound (bf16 rounding of 512 addends)
+            assert float((a1[k] - a0[k]).abs().max()) < 5e-3, k
+            continue
+        tol = 3e-2 if k.endswith("rstd") else 2.5e-2
         assert rel(a1[k], a0[k]) < tol, (k, rel(a1[k], a0[k]))
     assert rel(g1, g0) < 3e-2
 

@@ -109,7 +109,7 @@ _SIGS = {
     "vct_layer_ss_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_layer_ss_stream_chunks": (i64, [C.c_int, C.c_int]),
     "vct_ss_pack": (C.c_int, [C.POINTER(SsPackSeg), C.c_int, vp, vp]),
-    "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), vp]),
+    "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), C.c_int, vp]),
     "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vct_linear_ln_fwd": (C.c_int, [C.POINTER(LinearLnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),

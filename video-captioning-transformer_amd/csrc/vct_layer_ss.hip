@@ -28,6 +28,7 @@
 // stores in the epilogue.  Everything the unfused backward kernels read (qkv, o, a, LayerNorm statistics, pre-activation, dropped
 // activation, ...) is first completed in an LDS panel and then copied to HBM with 16-byte row-contiguous stores by all 512 threads;
 // the dropout counter streams are those of the unfused kernels, so the unfused backward runs unchanged behind this forward.
+#include <cstring>
 #include "vct_attn_core.h"
 
 namespace vct {
@@ -40,19 +41,19 @@ constexpr int SS_KVSTR = 2 * SS_D + 8;             // k | v panel of the memory 
 constexpr int SS_R0 = 0, SS_R1A = SS_SLOT, SS_R1B = 2 * SS_SLOT, SS_R1C = 3 * SS_SLOT;
 constexpr int SS_RM = 4 * SS_SLOT;                 // memory rows of this sample: 16 x 520 bf16
 constexpr int SS_RED = SS_RM + 16 * SS_PSTR * 2;   // LayerNorm partials: 2 x [8 waves][32 rows] fp32
-constexpr int SS_LDS = SS_RED + 2 * SS_NW * 32 * 4;
+constexpr int SS_B1 = SS_RED + 2 * SS_NW * 32 * 4;   // linear1 bias (fp32, ff <= 2048): read by the pipelined feed-forward epilogue
+constexpr int SS_FF_MAX = 2048;
+constexpr int SS_B2 = SS_B1 + SS_FF_MAX * 4;           // linear2 bias (fp32, 512)
+constexpr int SS_LDS = SS_B2 + SS_D * 4;
 constexpr long SS_CHUNK = 32768;                   // bf16 elements per K chunk of the stream (64 KiB: 8 waves x 8 fragments x 1 KiB)
 static_assert(SS_LDS <= 160 * 1024, "LDS budget");
 static_assert(32 * SS_QSTR * 2 <= 3 * SS_SLOT && 16 * SS_KVSTR * 2 <= SS_SLOT, "panel slots");
 
 struct SsNorm { const float* g; const float* b; bf16_t* y; float* mean; float* rstd; };
 
-struct SsLayerP {
-  int B, L, Lm;                      // samples, rows per sample (<= 32), memory rows per sample (<= 16; decoder layers)
-  int ff, act, last, causal;
-  const bf16_t* wpk; int nchunks;    // packed weight stream of this layer (stream order, see vct_ss_pack)
-  const bf16_t* x;                   // [B*L, 512] layer input
-  const bf16_t* mem;                 // [B*Lm, 512] encoder memory (decoder layers)
+constexpr int SS_MAXL = 4;           // layers per launch (kernel-argument budget); deeper stacks take several launches
+
+struct SsLayerW {                    // what differs from layer to layer
   // self-attention block
   const float* b_qkv; const float* b_o;
   bf16_t* qkv; bf16_t* o; bf16_t* a;
@@ -65,14 +66,38 @@ struct SsLayerP {
   const float* b1; const float* b2;
   bf16_t* hpre; bf16_t* h; bf16_t* f;
   SsNorm n3;
-  SsNorm nf;                         // stack-final norm (last != 0)
+  uint32_t site_sa, site_n1, site_ca, site_n2, site_ff, site_n3;
+};
+
+struct SsLayerP {
+  int B, L, Lm;                      // samples, rows per sample (<= 32), memory rows per sample (<= 16; decoder layers)
+  int ff, act, last, causal, nl;
+  const bf16_t* wpk; int nchunks;    // packed weight stream of ALL nl layers, back to back (stream order, see vct_ss_pack)
+  const bf16_t* x;                   // [B*L, 512] input of the first layer
+  const bf16_t* mem;                 // [B*Lm, 512] encoder memory (decoder layers)
+  SsNorm nf;                         // stack-final norm behind the last layer (last != 0)
   // masks of the self-attention (as vct_attn_desc)
   const uint8_t* key_pad; int key_pad_shift;
   const int64_t* key_ids; long key_ids_bs; long pad_id;
   // dropout
   const uint32_t* seed; float p_drop;
-  uint32_t site_sa, site_n1, site_ca, site_n2, site_ff, site_n3;
+  SsLayerW lw[SS_MAXL];
+#ifdef SS_STAMPS
+  unsigned long long* dbg;           // development build (tools/ss_layer_stamps.hip): [B][64] cycle stamps of wave 0 (last layer of the launch)
+#endif
 };
+#ifdef SS_STAMPS
+#define SS_STAMP(i) do { if (tid == 0) p.dbg[(long)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SS_STAMP(i) do { } while (0)
+#endif
+
+// workgroup barrier that orders LDS traffic only: the weight prefetch (and the panel copies' stores) stay in flight across it
+__device__ __forceinline__ void ss_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 // ---- weight stream: this lane's view of the layer's packed weights ------------------------------------------------------------------
 // chunk c of the stream = elements [c*32768, (c+1)*32768): wave w's 8 fragments (column tile t, k-step s) at w*4096 + (t*2+s)*512,
@@ -90,30 +115,46 @@ __device__ __forceinline__ void ws_fetch(WStream& ws, bf16x8 (&dst)[4][2]) {
 }
 
 // acc[m][t] += W_chunk-fragments x A-fragments for `nch` (even) chunks; A = LDS panel, this lane's pointer `a` already at
-// (row li, k-group lg*8), row-tile stride 16*astr, chunk kc0 first.  On entry buffer b0 holds the first chunk (in flight); on
-// exit b0 holds the first chunk of whatever comes next in the stream.
+// (row li, k-group lg*8), row-tile stride 16*astr, chunk kc0 first.  The stream runs TWO chunks ahead with two register buffers: on
+// entry b0 / b1 hold the first two chunks (in flight), each buffer is re-fetched right behind the MFMAs that read it, and on exit they
+// hold the first two chunks of whatever comes next in the stream -- so an epilogue between two products has 16 KB per wave in flight.
 template <int MT>
-__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc0, const int nch, WStream& ws,
-                                          bf16x8 (&b0)[4][2], bf16x8 (&b1)[4][2]) {
-  auto step = [&](bf16x8 (&b)[4][2], const int kc) {
-    bf16x8 af[MT][2];
+__device__ __forceinline__ void gemm_step(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc, const bf16x8 (&b)[4][2]) {
+  bf16x8 af[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) af[m][s] = *reinterpret_cast<const bf16x8*>(a + m * 16 * astr + kc * 64 + s * 32);
+#pragma unroll
+  for (int s = 0; s < 2; s++)
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int s = 0; s < 2; s++) af[m][s] = *reinterpret_cast<const bf16x8*>(a + m * 16 * astr + kc * 64 + s * 32);
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t][s], af[m][s], acc[m][t], 0, 0, 0);
-  };
+      for (int t = 0; t < 4; t++) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t][s], af[m][s], acc[m][t], 0, 0, 0);
+}
+template <int MT>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc0, const int nch, WStream& ws,
+                                          bf16x8 (&b0)[4][2], bf16x8 (&b1)[4][2]) {
   for (int c = 0; c < nch; c += 2) {
-    ws_fetch(ws, b1);
-    step(b0, kc0 + c);
+    gemm_step<MT>(acc, a, astr, kc0 + c, b0);
     ws_fetch(ws, b0);
-    step(b1, kc0 + c + 1);
+    gemm_step<MT>(acc, a, astr, kc0 + c + 1, b1);
+    ws_fetch(ws, b1);
   }
+}
+// the same for exactly 8 chunks, fully unrolled, with cb(k) (k = 0..7: independent vector work) issued in front of K step k
+template <int MT, class F>
+__device__ __forceinline__ void wave_gemm8_cb(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, WStream& ws, bf16x8 (&b0)[4][2],
+                                              bf16x8 (&b1)[4][2], F&& cb) {
+  static_for<4>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    cb(std::integral_constant<int, 2 * i>{});
+    gemm_step<MT>(acc, a, astr, 2 * i, b0);
+    ws_fetch(ws, b0);
+    cb(std::integral_constant<int, 2 * i + 1>{});
+    gemm_step<MT>(acc, a, astr, 2 * i + 1, b1);
+    ws_fetch(ws, b1);
+  });
 }
 
 template <int MT> __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][4]) {
@@ -131,10 +172,12 @@ __device__ __forceinline__ void load_bias4(float4 (&bv)[4], const float* bias, c
 struct alignas(8) BV4 { bf16_t e[4]; };
 struct alignas(16) BV8s { bf16_t e[8]; };
 
-// rows [0, rows) x cols [0, ncols) of an LDS panel -> global [row0 + r][col0 ..], 16 bytes per thread and step
-__device__ __forceinline__ void panel_to_global(const bf16_t* panel, const int pstr, const int rows, const int ncols, bf16_t* g, const long ld,
+// rows [0, rows) x NCOLS columns of an LDS panel -> global [row0 + r][col0 ..], 16 bytes per thread and step
+template <int NCOLS>
+__device__ __forceinline__ void panel_to_global(const bf16_t* panel, const int pstr, const int rows, bf16_t* g, const long ld,
                                                 const long row0, const int col0, const int tid) {
-  const int vpr = ncols >> 3, total = rows * vpr;
+  constexpr int vpr = NCOLS / 8;
+  const int total = rows * vpr;
   for (int v = tid; v < total; v += SS_NT) {
     const int r = v / vpr, c = (v - r * vpr) * 8;
     *reinterpret_cast<BV8s*>(g + (row0 + r) * ld + col0 + c) = *reinterpret_cast<const BV8s*>(panel + r * pstr + c);
@@ -153,6 +196,14 @@ __device__ __forceinline__ void global_to_panel(bf16_t* panel, const int pstr, c
       for (int j = 0; j < 8; j++) val.e[j] = 0;
     }
     *reinterpret_cast<BV8s*>(panel + r * pstr + c) = val;
+  }
+}
+
+__device__ __forceinline__ void load_gb(float4 (&gm)[4], float4 (&bt)[4], const SsNorm& n, const int ecol) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    gm[t] = *reinterpret_cast<const float4*>(n.g + ecol + t * 16);
+    bt[t] = *reinterpret_cast<const float4*>(n.b + ecol + t * 16);
   }
 }
 
@@ -179,12 +230,10 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
                                        const Dropout& dr, const long grow0, const int L, bf16_t* AP, bf16_t* YP, bf16_t* Y2P, float* red,
                                        const int wave, const int li, const int lg) {
   const int colw = wave * 64 + lg * 4;
+  // gamma / beta: issued now, first used two barriers further down -- they land behind the 16 KB of weight prefetch this wave has in
+  // flight (in-order return) without anybody waiting for them
   float4 gm[4], bt[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    gm[t] = *reinterpret_cast<const float4*>(n.g + colw + t * 16);
-    bt[t] = *reinterpret_cast<const float4*>(n.b + colw + t * 16);
-  }
+  load_gb(gm, bt, n, colw);
   float part[MT];
 #pragma unroll
   for (int m = 0; m < MT; m++) {
@@ -214,7 +263,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
 #pragma unroll
       for (int m = 0; m < MT; m++) red0[wave * 32 + m * 16 + li] = part[m];
     }
-    __syncthreads();
+    ss_barrier();
     float sq[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
@@ -233,7 +282,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
 #pragma unroll
       for (int m = 0; m < MT; m++) red1[wave * 32 + m * 16 + li] = sq[m];
     }
-    __syncthreads();
+    ss_barrier();
 #pragma unroll
     for (int m = 0; m < MT; m++) {
       float v = 0.0f;
@@ -381,12 +430,11 @@ __device__ __forceinline__ unsigned long long ss_padmask(const SsLayerP& p, cons
   return __ballot(lane >= p.key_pad_shift && lane < p.L && v != 0);
 }
 
-template <bool CROSS>
+template <bool CROSS, int MT>
 __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int b = blockIdx.x, L = p.L;
   const long grow0 = (long)b * L;
   bf16_t* R0 = reinterpret_cast<bf16_t*>(smem + SS_R0);
@@ -395,154 +443,221 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
   bf16_t* R1C = reinterpret_cast<bf16_t*>(smem + SS_R1C);
   bf16_t* RMp = reinterpret_cast<bf16_t*>(smem + SS_RM);
   float* red = reinterpret_cast<float*>(smem + SS_RED);
+  float* b1s = reinterpret_cast<float*>(smem + SS_B1);
+  float* b2s = reinterpret_cast<float*>(smem + SS_B2);
 
   WStream ws;
-  ws.p = p.wpk + (long)wave * 4096 + lane * 8;
+  ws.p = p.wpk + (long)wave * 4096 + lane0 * 8;
   ws.last = ws.p + (long)(p.nchunks - 1) * SS_CHUNK;
   bf16x8 b0[4][2], b1[4][2];
-  ws_fetch(ws, b0);                                        // the stream starts before the first activation byte is here
+  ws_fetch(ws, b0);                                        // the stream starts before the first activation byte is here,
+  ws_fetch(ws, b1);                                        // two chunks ahead: both buffers are in flight between products
 
-  global_to_panel(R0, SS_PSTR, L, 32, p.x, SS_D, grow0, tid);
-  if constexpr (CROSS) global_to_panel(RMp, SS_PSTR, p.Lm, 16, p.mem, SS_D, (long)b * p.Lm, tid);
-  const unsigned long long padmask = ss_padmask(p, b, lane);
-  __syncthreads();
-
-  const int aoff = li * SS_PSTR + lg * 8;                  // this lane's A-fragment origin inside a [32][SS_PSTR] panel
-  f32x4 acc[2][4];
-  float4 bv[4];
-
-  // ---- self-attention block ----------------------------------------------------------------------------------------------------------
-  for (int nb = 0; nb < 3; nb++) {                         // q | k | v = x W_in^T + b_in  -> panel [32][1544] in R1A..R1C
-    load_bias4(bv, p.b_qkv, nb * 512 + wave * 64, lg);
-    acc_zero<2>(acc);
-    wave_gemm<2>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-    epi_store<2>(acc, bv, R1A, SS_QSTR, nb * 512 + wave * 64, li, lg);
-  }
-  // residual rows of the out_proj epilogue: from HBM (the x panel is about to become the attention output panel)
-  BV4 res[2][4];
-#pragma unroll
-  for (int m = 0; m < 2; m++)
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const long r = grow0 + min(m * 16 + li, L - 1);
-      res[m][t] = *reinterpret_cast<const BV4*>(p.x + r * SS_D + wave * 64 + t * 16 + lg * 4);
-    }
-  __syncthreads();
-  panel_to_global(R1A, SS_QSTR, L, 3 * SS_D, p.qkv, 3 * SS_D, grow0, 0, tid);
-  {
-    const Dropout dr = make_dropout(p.seed, p.site_sa, p.p_drop);
-    ss_attn_wave(R1A + wave * 64, SS_QSTR, R1A + SS_D + wave * 64, R1A + 2 * SS_D + wave * 64, SS_QSTR, L, L, p.causal, padmask, dr,
-                 b * SS_H + wave, R0 + wave * 64, lane);
-  }
-  __syncthreads();
-  panel_to_global(R0, SS_PSTR, L, SS_D, p.o, SS_D, grow0, 0, tid);
-  {                                                        // a = o W_o^T + b_o;  x1 = LN1(x + drop(a))
-    load_bias4(bv, p.b_o, wave * 64, lg);
-    acc_zero<2>(acc);
-    wave_gemm<2>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-    const Dropout dr = make_dropout(p.seed, p.site_n1, p.p_drop);
-    epi_ln<2>(acc, bv, res, p.n1, nullptr, dr, grow0, L, R1A, R1B, nullptr, red, wave, li, lg);
-  }
-  __syncthreads();
-  panel_to_global(R1A, SS_PSTR, L, SS_D, p.a, SS_D, grow0, 0, tid);
-  panel_to_global(R1B, SS_PSTR, L, SS_D, p.n1.y, SS_D, grow0, 0, tid);
-
-  // panels of the feed-forward phase (see the slot plan in DESIGN.md): input rows, pre-activation, activation, f, y, y2
+  global_to_panel(R0, SS_PSTR, L, MT * 16, p.x, SS_D, grow0, tid0);
+  if constexpr (CROSS) global_to_panel(RMp, SS_PSTR, p.Lm, 16, p.mem, SS_D, (long)b * p.Lm, tid0);
+  const unsigned long long padmask = ss_padmask(p, b, lane0);
+  // panels of the feed-forward phase (slot plan: DESIGN.md): input rows, the two activation buffers, f, y (= the next layer's x), y2
   bf16_t* FIN = CROSS ? R0 : R1B;
-  bf16_t* HPRE = CROSS ? R1A : R1C;
-  bf16_t* HP = CROSS ? R1B : R0;
-  bf16_t* FP = CROSS ? R1C : R1A;
-  bf16_t* YP = CROSS ? R1A : R1C;
-  bf16_t* Y2P = CROSS ? R1B : R0;
+  bf16_t* HP0 = CROSS ? R1B : R0;
+  bf16_t* HP1 = R1C;
+  bf16_t* FP = R1A;
+  bf16_t* YP = R0;
+  bf16_t* Y2P = R1C;
 
-  if constexpr (CROSS) {
-    // ---- cross-attention block -------------------------------------------------------------------------------------------------------
-    const int Lm = p.Lm;
-    load_bias4(bv, p.b_cq, wave * 64, lg);                 // q = x1 W_q^T + b_q -> R1C
-    acc_zero<2>(acc);
-    wave_gemm<2>(acc, R1B + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-    epi_store<2>(acc, bv, R1C, SS_PSTR, wave * 64, li, lg);
-    for (int nb = 0; nb < 2; nb++) {                       // k | v = mem W_kv^T + b_kv -> panel [16][1032] in R0
-      f32x4 acm[1][4];
-      load_bias4(bv, p.b_ckv, nb * 512 + wave * 64, lg);
-      acc_zero<1>(acm);
-      wave_gemm<1>(acm, RMp + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-      epi_store<1>(acm, bv, R0, SS_KVSTR, nb * 512 + wave * 64, li, lg);
+  // the per-layer table is indexed with a loop variable: read it through the kernel-argument segment (scalar loads) -- indexing the
+  // by-value argument itself makes the compiler copy all of it to scratch
+  typedef const __attribute__((address_space(4))) SsLayerP* KargP;
+  const KargP kp = (KargP)__builtin_amdgcn_kernarg_segment_ptr();
+  for (int l = 0; l < p.nl; l++) {
+    // per-lane indices, re-materialised per layer behind an opaque barrier: left visible, the compiler hoists every address
+    // derived from them out of the layer loop and keeps ~80 loop-invariant registers alive through the whole body (spills)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int aoff = li * SS_PSTR + lg * 8;                // this lane's A-fragment origin inside a [32][SS_PSTR] panel
+    const int ecol = wave * 64 + lg * 4;                   // this lane's first epilogue column inside a 512-column block (+ t*16)
+    const __attribute__((address_space(4))) SsLayerW& w = kp->lw[l];     // fields are fetched (scalar loads) where they are used
+    auto nrm = [](const __attribute__((address_space(4))) SsNorm& n) { return SsNorm{n.g, n.b, n.y, n.mean, n.rstd}; };
+    const bool fin = p.last && l == p.nl - 1;
+    // the layer's linear1 bias -> LDS (the x panel of layers l > 0 is already in R0: the previous layer's output)
+    for (int v = tid; v < (p.ff >> 2); v += SS_NT) reinterpret_cast<float4*>(b1s)[v] = reinterpret_cast<const float4*>(w.b1)[v];
+    if (tid < SS_D / 4) reinterpret_cast<float4*>(b2s)[tid] = reinterpret_cast<const float4*>(w.b2)[tid];
+    SS_STAMP(0);
+    ss_barrier();
+    SS_STAMP(1);
+
+    f32x4 acc[MT][4];
+    float4 bv[4];
+    // ---- self-attention block --------------------------------------------------------------------------------------------------------
+    for (int nb = 0; nb < 3; nb++) {                       // q | k | v = x W_in^T + b_in  -> panel [32][1544] in R1A..R1C
+      load_bias4(bv, w.b_qkv, nb * 512 + wave * 64, lg);
+      acc_zero<MT>(acc);
+      wave_gemm<MT>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      epi_store<MT>(acc, bv, R1A, SS_QSTR, nb * 512 + wave * 64, li, lg);
     }
-    __syncthreads();
-    panel_to_global(R1C, SS_PSTR, L, SS_D, p.cq, SS_D, grow0, 0, tid);
-    panel_to_global(R0, SS_KVSTR, Lm, 2 * SS_D, p.ckv, 2 * SS_D, (long)b * Lm, 0, tid);
+    // residual rows of the out_proj epilogue: out of the x panel, which is about to become the attention output panel
+    BV4 res[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R0 + (m * 16 + li) * SS_PSTR + ecol + t * 16);
+    SS_STAMP(2);
+    ss_barrier();
+    SS_STAMP(3);
+    panel_to_global<3 * SS_D>(R1A, SS_QSTR, L, w.qkv, 3 * SS_D, grow0, 0, tid);
+    SS_STAMP(4);
     {
-      const Dropout dr = make_dropout(p.seed, p.site_ca, p.p_drop);
-      // rows >= Lm of the 16-row k | v panel: computed from zero memory rows = the bias, finite
-      ss_attn_wave(R1C + wave * 64, SS_PSTR, R0 + wave * 64, R0 + SS_D + wave * 64, SS_KVSTR, L, Lm, 0, 0ull, dr, b * SS_H + wave,
-                   R1A + wave * 64, lane);
+      const Dropout dr = make_dropout(p.seed, w.site_sa, p.p_drop);
+      ss_attn_wave(R1A + wave * 64, SS_QSTR, R1A + SS_D + wave * 64, R1A + 2 * SS_D + wave * 64, SS_QSTR, L, L, p.causal, padmask, dr,
+                   b * SS_H + wave, R0 + wave * 64, lane);
     }
-    __syncthreads();
-    panel_to_global(R1A, SS_PSTR, L, SS_D, p.co, SS_D, grow0, 0, tid);
-    {                                                      // a2 = o2 W_o^T + b_o;  x2 = LN2(x1 + drop(a2)); residual x1 still in R1B
-#pragma unroll
-      for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R1B + (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4);
-      load_bias4(bv, p.b_co, wave * 64, lg);
-      acc_zero<2>(acc);
-      wave_gemm<2>(acc, R1A + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-      const Dropout dr = make_dropout(p.seed, p.site_n2, p.p_drop);
-      epi_ln<2>(acc, bv, res, p.n2, nullptr, dr, grow0, L, R1C, R0, nullptr, red, wave, li, lg);
+    SS_STAMP(5);
+    ss_barrier();
+    SS_STAMP(6);
+    panel_to_global<SS_D>(R0, SS_PSTR, L, w.o, SS_D, grow0, 0, tid);
+    SS_STAMP(7);
+    {                                                      // a = o W_o^T + b_o;  x1 = LN1(x + drop(a))
+      load_bias4(bv, w.b_o, wave * 64, lg);
+      acc_zero<MT>(acc);
+      wave_gemm<MT>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      SS_STAMP(8);
+      const Dropout dr = make_dropout(p.seed, w.site_n1, p.p_drop);
+      epi_ln<MT>(acc, bv, res, nrm(w.n1), nullptr, dr, grow0, L, R1A, R1B, nullptr, red, wave, li, lg);
+      SS_STAMP(9);
     }
-    __syncthreads();
-    panel_to_global(R1C, SS_PSTR, L, SS_D, p.ca, SS_D, grow0, 0, tid);
-    panel_to_global(R0, SS_PSTR, L, SS_D, p.n2.y, SS_D, grow0, 0, tid);
-  }
+    ss_barrier();
+    panel_to_global<SS_D>(R1A, SS_PSTR, L, w.a, SS_D, grow0, 0, tid);
+    panel_to_global<SS_D>(R1B, SS_PSTR, L, w.n1.y, SS_D, grow0, 0, tid);
+    SS_STAMP(10);
 
-  // ---- feed-forward block: ff / 512 chunks of (linear1 block -> GELU, dropout -> linear2 K slice) ------------------------------------
-  f32x4 facc[2][4];
-  acc_zero<2>(facc);
-  const Dropout drf = make_dropout(p.seed, p.site_ff, p.p_drop);
-  const int nj = p.ff >> 9;
-  for (int j = 0; j < nj; j++) {
-    load_bias4(bv, p.b1, j * 512 + wave * 64, lg);
-    acc_zero<2>(acc);
-    wave_gemm<2>(acc, FIN + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-    if (j > 0) __syncthreads();                            // the previous chunk's panels have been copied out / consumed by linear2
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-      const uint32_t grow = (uint32_t)(grow0 + m * 16 + li);
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int col = j * 512 + wave * 64 + t * 16 + lg * 4;
-        float dm[4];
-        drop_mults<4>(drf, grow * (uint32_t)p.ff + (uint32_t)col, dm);
-        const vf2 x0 = {acc[m][t][0] + bv[t].x, acc[m][t][1] + bv[t].y}, x1 = {acc[m][t][2] + bv[t].z, acc[m][t][3] + bv[t].w};
-        BV4 pv, hv;
-        pv.e[0] = f2bf(x0[0]); pv.e[1] = f2bf(x0[1]); pv.e[2] = f2bf(x1[0]); pv.e[3] = f2bf(x1[1]);
-        const vf2 a0 = act_fast_f2(p.act, x0) * vf2{dm[0], dm[1]}, a1 = act_fast_f2(p.act, x1) * vf2{dm[2], dm[3]};
-        hv.e[0] = f2bf(a0[0]); hv.e[1] = f2bf(a0[1]); hv.e[2] = f2bf(a1[0]); hv.e[3] = f2bf(a1[1]);
-        const int off = (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4;
-        *reinterpret_cast<BV4*>(HPRE + off) = pv;
-        *reinterpret_cast<BV4*>(HP + off) = hv;
+    if constexpr (CROSS) {
+      // ---- cross-attention block -----------------------------------------------------------------------------------------------------
+      const int Lm = p.Lm;
+      load_bias4(bv, w.b_cq, wave * 64, lg);               // q = x1 W_q^T + b_q -> R1C
+      acc_zero<MT>(acc);
+      wave_gemm<MT>(acc, R1B + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      epi_store<MT>(acc, bv, R1C, SS_PSTR, wave * 64, li, lg);
+      SS_STAMP(11);
+      for (int nb = 0; nb < 2; nb++) {                     // k | v = mem W_kv^T + b_kv -> panel [16][1032] in R0
+        f32x4 acm[1][4];
+        load_bias4(bv, w.b_ckv, nb * 512 + wave * 64, lg);
+        acc_zero<1>(acm);
+        wave_gemm<1>(acm, RMp + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+        epi_store<1>(acm, bv, R0, SS_KVSTR, nb * 512 + wave * 64, li, lg);
       }
+      SS_STAMP(12);
+      ss_barrier();
+      panel_to_global<SS_D>(R1C, SS_PSTR, L, w.cq, SS_D, grow0, 0, tid);
+      panel_to_global<2 * SS_D>(R0, SS_KVSTR, Lm, w.ckv, 2 * SS_D, (long)b * Lm, 0, tid);
+      SS_STAMP(13);
+      {
+        const Dropout dr = make_dropout(p.seed, w.site_ca, p.p_drop);
+        // rows >= Lm of the 16-row k | v panel: computed from zero memory rows = the bias, finite
+        ss_attn_wave(R1C + wave * 64, SS_PSTR, R0 + wave * 64, R0 + SS_D + wave * 64, SS_KVSTR, L, Lm, 0, 0ull, dr, b * SS_H + wave,
+                     R1A + wave * 64, lane);
+      }
+      SS_STAMP(14);
+      ss_barrier();
+      panel_to_global<SS_D>(R1A, SS_PSTR, L, w.co, SS_D, grow0, 0, tid);
+      SS_STAMP(15);
+      {                                                    // a2 = o2 W_o^T + b_o;  x2 = LN2(x1 + drop(a2)); residual x1 still in R1B
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R1B + (m * 16 + li) * SS_PSTR + ecol + t * 16);
+        load_bias4(bv, w.b_co, wave * 64, lg);
+        acc_zero<MT>(acc);
+        wave_gemm<MT>(acc, R1A + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+        SS_STAMP(16);
+        const Dropout dr = make_dropout(p.seed, w.site_n2, p.p_drop);
+        epi_ln<MT>(acc, bv, res, nrm(w.n2), nullptr, dr, grow0, L, R1C, R0, nullptr, red, wave, li, lg);
+        SS_STAMP(17);
+      }
+      ss_barrier();
+      panel_to_global<SS_D>(R1C, SS_PSTR, L, w.ca, SS_D, grow0, 0, tid);
+      panel_to_global<SS_D>(R0, SS_PSTR, L, w.n2.y, SS_D, grow0, 0, tid);
+      SS_STAMP(18);
     }
-    __syncthreads();
-    panel_to_global(HPRE, SS_PSTR, L, SS_D, p.hpre, p.ff, grow0, j * 512, tid);
-    panel_to_global(HP, SS_PSTR, L, SS_D, p.h, p.ff, grow0, j * 512, tid);
-    wave_gemm<2>(facc, HP + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-  }
-  {                                                        // f = h W_2^T + b_2;  y = LN(x_in + drop(f)) [; y2 = LN_final(y)]
+
+    // ---- feed-forward block, software-pipelined over the ff / 512 chunks ----------------------------------------------------------------
+    //   linear1(0) | [linear1(j+1) GEMM with the GELU / dropout epilogue of chunk j between its K steps] | barrier | linear2(j) K slice | ...
+    // The epilogue of a chunk is ~9 k cycles of vector ALU work that nothing else in the workgroup could overlap; issued between the
+    // K steps of the NEXT chunk's linear1 it runs in the shadow of that product's weight stream.  The activation panel is double-
+    // buffered (one barrier per chunk); the pre-activation goes to HBM straight from the registers (8-byte stores).
+    f32x4 facc[MT][4];
+    BV4 hpk[MT][4];                                          // pre-activation of the chunk whose epilogue is pending, as stored (bf16)
+    acc_zero<MT>(facc);
+    const Dropout drf = make_dropout(p.seed, w.site_ff, p.p_drop);
+    const int nj = p.ff >> 9;
+    auto ffn_pre = [&](const int j) {                        // hpre(j) = bf16(acc + b1): to HBM now, kept packed for the pipelined GELU
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(FIN + (m * 16 + li) * SS_PSTR + wave * 64 + t * 16 + lg * 4);
-    load_bias4(bv, p.b2, wave * 64, lg);
-    __syncthreads();                                       // the last chunk's copies and linear2 reads are done: HPRE / HP become y / y2
-    const Dropout dr = make_dropout(p.seed, p.site_n3, p.p_drop);
-    epi_ln<2>(facc, bv, res, p.n3, p.last ? &p.nf : nullptr, dr, grow0, L, FP, YP, Y2P, red, wave, li, lg);
+        for (int t = 0; t < 4; t++) {
+          const int row = m * 16 + li, col = j * 512 + ecol + t * 16;
+          const float4 bb = *reinterpret_cast<const float4*>(b1s + col);
+          BV4 pv;
+          pv.e[0] = f2bf(acc[m][t][0] + bb.x); pv.e[1] = f2bf(acc[m][t][1] + bb.y);
+          pv.e[2] = f2bf(acc[m][t][2] + bb.z); pv.e[3] = f2bf(acc[m][t][3] + bb.w);
+          hpk[m][t] = pv;
+          if (row < L) *reinterpret_cast<BV4*>(w.hpre + (grow0 + row) * p.ff + col) = pv;
+        }
+    };
+    auto ffn_tile = [&](const int j, auto K) {               // GELU + dropout of ONE 16 x 16 tile of chunk j -> activation panel
+      constexpr int k = decltype(K)::value;
+      if constexpr (k < MT * 4) {
+        constexpr int m = k / 4, t = k % 4;
+        const int row = m * 16 + li;
+        const int col = j * 512 + ecol + t * 16;
+        float dm[4];
+        drop_mults<4>(drf, (uint32_t)(grow0 + row) * (uint32_t)p.ff + (uint32_t)col, dm);
+        // the activation is built on the pre-activation AS STORED (bf16): what the backward's GELU' reads
+        const vf2 x0 = {bf2f(hpk[m][t].e[0]), bf2f(hpk[m][t].e[1])}, x1 = {bf2f(hpk[m][t].e[2]), bf2f(hpk[m][t].e[3])};
+        const vf2 a0 = act_fast_f2(p.act, x0) * vf2{dm[0], dm[1]}, a1 = act_fast_f2(p.act, x1) * vf2{dm[2], dm[3]};
+        BV4 hv;
+        hv.e[0] = f2bf(a0[0]); hv.e[1] = f2bf(a0[1]); hv.e[2] = f2bf(a1[0]); hv.e[3] = f2bf(a1[1]);
+        *reinterpret_cast<BV4*>(((j & 1) ? HP1 : HP0) + row * SS_PSTR + ecol + t * 16) = hv;
+      }
+    };
+    acc_zero<MT>(acc);
+    wave_gemm<MT>(acc, FIN + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+    ffn_pre(0);
+    SS_STAMP(20);
+    for (int j = 0; j < nj; j++) {
+      if (j + 1 < nj) {
+        acc_zero<MT>(acc);
+        wave_gemm8_cb<MT>(acc, FIN + aoff, SS_PSTR, ws, b0, b1, [&](auto K) { ffn_tile(j, K); });
+      } else {
+        static_for<MT * 4>([&](auto K) { ffn_tile(j, K); });
+      }
+      SS_STAMP(21 + 4 * j);
+      ss_barrier();
+      bf16_t* HP = (j & 1) ? HP1 : HP0;
+      panel_to_global<SS_D>(HP, SS_PSTR, L, w.h, p.ff, grow0, j * 512, tid);
+      SS_STAMP(22 + 4 * j);
+      wave_gemm<MT>(facc, HP + aoff, SS_PSTR, 0, 8, ws, b0, b1);
+      if (j + 1 < nj) ffn_pre(j + 1);
+      SS_STAMP(23 + 4 * j);
+    }
+    {                                                      // f = h W_2^T + b_2;  y = LN(x_in + drop(f)) [; y2 = LN_final(y)]
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(FIN + (m * 16 + li) * SS_PSTR + ecol + t * 16);
+      load_bias4(bv, b2s, wave * 64, lg);
+      ss_barrier();                                        // the last chunk's copy and linear2 reads are done: the activation buffers become y / y2
+      const Dropout dr = make_dropout(p.seed, w.site_n3, p.p_drop);
+      const SsNorm nfl = p.nf;                             // (a pointer into the by-value argument would put all of it into scratch)
+      epi_ln<MT>(facc, bv, res, nrm(w.n3), fin ? &nfl : nullptr, dr, grow0, L, FP, YP, Y2P, red, wave, li, lg);
+      SS_STAMP(40);
+    }
+    ss_barrier();
+    panel_to_global<SS_D>(FP, SS_PSTR, L, w.f, SS_D, grow0, 0, tid);
+    panel_to_global<SS_D>(YP, SS_PSTR, L, w.n3.y, SS_D, grow0, 0, tid);
+    if (fin) panel_to_global<SS_D>(Y2P, SS_PSTR, L, p.nf.y, SS_D, grow0, 0, tid);
+    SS_STAMP(41);
+    // the next layer's x is YP = R0 (rows >= L: finite LayerNorm outputs of finite rows)
   }
-  __syncthreads();
-  panel_to_global(FP, SS_PSTR, L, SS_D, p.f, SS_D, grow0, 0, tid);
-  panel_to_global(YP, SS_PSTR, L, SS_D, p.n3.y, SS_D, grow0, 0, tid);
-  if (p.last) panel_to_global(Y2P, SS_PSTR, L, SS_D, p.nf.y, SS_D, grow0, 0, tid);
 }
 
 // ---- stream-order packing of weight blocks ---------------------------------------------------------------------------------------------
@@ -570,7 +685,7 @@ using namespace vct;
 
 extern "C" int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm) {
   if (dtype != VCT_BF16 || d != SS_D || H != SS_H) return 0;
-  if (ff < 512 || (ff % 512) != 0) return 0;
+  if (ff < 512 || (ff % 512) != 0 || ff > SS_FF_MAX) return 0;
   if (L < 1 || L > 32) return 0;
   if (Lm < 0 || Lm > 16) return 0;        // Lm = 0: encoder layer
   return 1;
@@ -605,49 +720,80 @@ extern "C" int vct_ss_pack(const vct_ss_pack_seg* segs, int nseg, void* dst, voi
   return VCT_OK;
 }
 
-extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* q, void* stream) {
-  if (q == nullptr) return VCT_E_ARG;
+extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, void* stream) {
+  if (layers == nullptr || n_layers < 1) return VCT_E_ARG;
+  const vct_layer_ss_desc* q = layers;
   const int cross = q->mem != nullptr;
   if (!vct_layer_ss_supported(q->dtype, q->d, q->H, q->ff, q->L, cross ? q->Lm : 0) || q->B < 1) return VCT_E_SHAPE;
   if (cross && q->Lm < 1) return VCT_E_SHAPE;
-  if (q->nchunks != vct_layer_ss_stream_chunks(q->ff, cross)) return VCT_E_SHAPE;
-  if (!q->wpk || !q->x || !q->b_qkv || !q->b_o || !q->qkv || !q->o || !q->a || !q->b1 || !q->b2 || !q->hpre || !q->h || !q->f) return VCT_E_ARG;
+  const int64_t per_layer = vct_layer_ss_stream_chunks(q->ff, cross);
+  if (!q->x || q->key_pad_shift < 0 || (q->key_pad != nullptr && q->key_pad_shift >= q->L)) return q->x ? VCT_E_SHAPE : VCT_E_ARG;
   auto norm_ok = [](const vct_ss_norm& n) { return n.gamma && n.beta && n.y && n.mean && n.rstd; };
-  if (!norm_ok(q->n1) || !norm_ok(q->n3) || (q->last && !norm_ok(q->nf))) return VCT_E_ARG;
-  if (cross && (!q->b_cq || !q->b_ckv || !q->b_co || !q->cq || !q->ckv || !q->co || !q->ca || !norm_ok(q->n2))) return VCT_E_ARG;
-  if (q->key_pad_shift < 0 || (q->key_pad != nullptr && q->key_pad_shift >= q->L)) return VCT_E_SHAPE;
-  const uintptr_t al = (uintptr_t)q->wpk | (uintptr_t)q->x | (uintptr_t)q->mem | (uintptr_t)q->qkv | (uintptr_t)q->o | (uintptr_t)q->a |
-                       (uintptr_t)q->cq | (uintptr_t)q->ckv | (uintptr_t)q->co | (uintptr_t)q->ca | (uintptr_t)q->hpre | (uintptr_t)q->h |
-                       (uintptr_t)q->f | (uintptr_t)q->n1.y | (uintptr_t)q->n2.y | (uintptr_t)q->n3.y | (uintptr_t)q->nf.y |
-                       (uintptr_t)q->b_qkv | (uintptr_t)q->b_o | (uintptr_t)q->b_cq | (uintptr_t)q->b_ckv | (uintptr_t)q->b_co |
-                       (uintptr_t)q->b1 | (uintptr_t)q->b2;
-  if (al & 15) return VCT_E_ALIGN;
-  SsLayerP p;
-  p.B = q->B; p.L = q->L; p.Lm = cross ? q->Lm : 0; p.ff = q->ff; p.act = q->act; p.last = q->last; p.causal = q->causal;
-  p.wpk = reinterpret_cast<const bf16_t*>(q->wpk); p.nchunks = (int)q->nchunks;
-  p.x = reinterpret_cast<const bf16_t*>(q->x); p.mem = reinterpret_cast<const bf16_t*>(q->mem);
-  p.b_qkv = q->b_qkv; p.b_o = q->b_o;
-  p.qkv = reinterpret_cast<bf16_t*>(q->qkv); p.o = reinterpret_cast<bf16_t*>(q->o); p.a = reinterpret_cast<bf16_t*>(q->a);
   auto cvt = [](const vct_ss_norm& n) { return SsNorm{n.gamma, n.beta, reinterpret_cast<bf16_t*>(n.y), n.mean, n.rstd}; };
-  p.n1 = cvt(q->n1); p.n2 = cvt(q->n2); p.n3 = cvt(q->n3); p.nf = cvt(q->nf);
-  p.b_cq = q->b_cq; p.b_ckv = q->b_ckv; p.b_co = q->b_co;
-  p.cq = reinterpret_cast<bf16_t*>(q->cq); p.ckv = reinterpret_cast<bf16_t*>(q->ckv); p.co = reinterpret_cast<bf16_t*>(q->co);
-  p.ca = reinterpret_cast<bf16_t*>(q->ca);
-  p.b1 = q->b1; p.b2 = q->b2;
-  p.hpre = reinterpret_cast<bf16_t*>(q->hpre); p.h = reinterpret_cast<bf16_t*>(q->h); p.f = reinterpret_cast<bf16_t*>(q->f);
-  p.key_pad = q->key_pad; p.key_pad_shift = q->key_pad_shift; p.key_ids = q->key_ids; p.key_ids_bs = q->key_ids_bs; p.pad_id = q->pad_id;
-  p.seed = q->seed; p.p_drop = q->p_drop;
-  p.site_sa = q->site_sa; p.site_n1 = q->site_n1; p.site_ca = q->site_ca; p.site_n2 = q->site_n2; p.site_ff = q->site_ff; p.site_n3 = q->site_n3;
-  hipStream_t st = (hipStream_t)stream;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[cross]) {
-    hipError_t e = cross ? hipFuncSetAttribute((const void*)layer_ss_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS)
-                         : hipFuncSetAttribute((const void*)layer_ss_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set[cross] = true;
+  for (int l = 0; l < n_layers; l++) {
+    const vct_layer_ss_desc& d = layers[l];
+    // one stack: every layer has the shape, masks, memory and dropout of the first; the packed streams lie back to back
+    if (d.dtype != q->dtype || d.B != q->B || d.L != q->L || d.Lm != q->Lm || d.d != q->d || d.H != q->H || d.ff != q->ff || d.act != q->act ||
+        d.causal != q->causal || d.key_pad_shift != q->key_pad_shift || d.mem != q->mem || d.key_pad != q->key_pad || d.key_ids != q->key_ids ||
+        d.key_ids_bs != q->key_ids_bs || d.pad_id != q->pad_id || d.seed != q->seed || d.p_drop != q->p_drop)
+      return VCT_E_ARG;
+    if (d.nchunks != per_layer) return VCT_E_SHAPE;
+    if (!d.wpk || (const char*)d.wpk != (const char*)q->wpk + (size_t)l * per_layer * SS_CHUNK * 2) return VCT_E_ARG;
+    if (d.last && l != n_layers - 1) return VCT_E_ARG;
+    if (!d.b_qkv || !d.b_o || !d.qkv || !d.o || !d.a || !d.b1 || !d.b2 || !d.hpre || !d.h || !d.f) return VCT_E_ARG;
+    if (!norm_ok(d.n1) || !norm_ok(d.n3) || (d.last && !norm_ok(d.nf))) return VCT_E_ARG;
+    if (cross && (!d.b_cq || !d.b_ckv || !d.b_co || !d.cq || !d.ckv || !d.co || !d.ca || !norm_ok(d.n2))) return VCT_E_ARG;
+    const uintptr_t al = (uintptr_t)d.wpk | (uintptr_t)d.x | (uintptr_t)d.mem | (uintptr_t)d.qkv | (uintptr_t)d.o | (uintptr_t)d.a |
+                         (uintptr_t)d.cq | (uintptr_t)d.ckv | (uintptr_t)d.co | (uintptr_t)d.ca | (uintptr_t)d.hpre | (uintptr_t)d.h |
+                         (uintptr_t)d.f | (uintptr_t)d.n1.y | (uintptr_t)d.n2.y | (uintptr_t)d.n3.y | (uintptr_t)d.nf.y |
+                         (uintptr_t)d.b_qkv | (uintptr_t)d.b_o | (uintptr_t)d.b_cq | (uintptr_t)d.b_ckv | (uintptr_t)d.b_co |
+                         (uintptr_t)d.b1 | (uintptr_t)d.b2;
+    if (al & 15) return VCT_E_ALIGN;
   }
-  if (cross) vct::launch(layer_ss_fwd_kernel<true>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
-  else vct::launch(layer_ss_fwd_kernel<false>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
-  VCT_CHECK_LAUNCH();
+  hipStream_t st = (hipStream_t)stream;
+  // rows <= 16: one 16-row MFMA tile per product (half the epilogue work, LDS reads and MFMAs of the two-tile form)
+  const int one = q->L <= 16 ? 1 : 0, which = cross * 2 + one;
+  static bool attr_set[4] = {false, false, false, false};
+  const void* fn = which == 0 ? (const void*)layer_ss_fwd_kernel<false, 2> : which == 1 ? (const void*)layer_ss_fwd_kernel<false, 1>
+                 : which == 2 ? (const void*)layer_ss_fwd_kernel<true, 2> : (const void*)layer_ss_fwd_kernel<true, 1>;
+  if (!attr_set[which]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set[which] = true;
+  }
+  for (int base = 0; base < n_layers; base += SS_MAXL) {       // SS_MAXL layers per launch; the hand-over between launches goes through y in HBM
+    const int nl = n_layers - base < SS_MAXL ? n_layers - base : SS_MAXL;
+    SsLayerP p;
+    memset(&p, 0, sizeof(p));
+    p.B = q->B; p.L = q->L; p.Lm = cross ? q->Lm : 0; p.ff = q->ff; p.act = q->act; p.causal = q->causal; p.nl = nl;
+    p.last = layers[base + nl - 1].last;
+    p.wpk = reinterpret_cast<const bf16_t*>(layers[base].wpk); p.nchunks = (int)(per_layer * nl);
+    p.x = reinterpret_cast<const bf16_t*>(base == 0 ? q->x : layers[base - 1].n3.y);
+    p.mem = reinterpret_cast<const bf16_t*>(q->mem);
+    p.nf = cvt(layers[base + nl - 1].nf);
+    p.key_pad = q->key_pad; p.key_pad_shift = q->key_pad_shift; p.key_ids = q->key_ids; p.key_ids_bs = q->key_ids_bs; p.pad_id = q->pad_id;
+    p.seed = q->seed; p.p_drop = q->p_drop;
+    for (int l = 0; l < nl; l++) {
+      const vct_layer_ss_desc& d = layers[base + l];
+      SsLayerW& w = p.lw[l];
+      w.b_qkv = d.b_qkv; w.b_o = d.b_o;
+      w.qkv = reinterpret_cast<bf16_t*>(d.qkv); w.o = reinterpret_cast<bf16_t*>(d.o); w.a = reinterpret_cast<bf16_t*>(d.a);
+      w.n1 = cvt(d.n1); w.n2 = cvt(d.n2); w.n3 = cvt(d.n3);
+      w.b_cq = d.b_cq; w.b_ckv = d.b_ckv; w.b_co = d.b_co;
+      w.cq = reinterpret_cast<bf16_t*>(d.cq); w.ckv = reinterpret_cast<bf16_t*>(d.ckv); w.co = reinterpret_cast<bf16_t*>(d.co);
+      w.ca = reinterpret_cast<bf16_t*>(d.ca);
+      w.b1 = d.b1; w.b2 = d.b2;
+      w.hpre = reinterpret_cast<bf16_t*>(d.hpre); w.h = reinterpret_cast<bf16_t*>(d.h); w.f = reinterpret_cast<bf16_t*>(d.f);
+      w.site_sa = d.site_sa; w.site_n1 = d.site_n1; w.site_ca = d.site_ca; w.site_n2 = d.site_n2; w.site_ff = d.site_ff; w.site_n3 = d.site_n3;
+    }
+#ifdef SS_STAMPS
+    p.dbg = g_ss_dbg;
+#endif
+    if (which == 0) vct::launch(layer_ss_fwd_kernel<false, 2>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+    else if (which == 1) vct::launch(layer_ss_fwd_kernel<false, 1>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+    else if (which == 2) vct::launch(layer_ss_fwd_kernel<true, 2>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+    else vct::launch(layer_ss_fwd_kernel<true, 1>, dim3(p.B), dim3(SS_NT), SS_LDS, st, p);
+    VCT_CHECK_LAUNCH();
+  }
   return VCT_OK;
 }

@@ -75,7 +75,7 @@ class ParamSet:
         # transposed copies of individual weight matrices in the compute dtype (name -> (tensor [cols, ld], start, end)): kept in
         # step with the shadow by refresh_shadow / cast_range / FusedAdam.step_range (refresh_transposed)
         self.transposed = {}
-        # STREAM-ORDER packed copies of whole layers (key -> [tensor, start, end, blocks, nchunks, dirty]): the operand of the
+        # STREAM-ORDER packed copies of whole stacks (key -> [tensor, chunks per layer, [[start, end, blocks, dirty] per layer]]): the operand of the
         # sample-stationary layer kernels (ops.layer_ss_fwd), kept in step with the shadow exactly like the eager transposed copies
         self.packed = {}
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
@@ -144,23 +144,32 @@ class ParamSet:
             ent[4] = self.version
         return ent[0]
 
-    def want_packed(self, key: str, names, blocks_fn):
-        """(stream, nchunks): the weights `names` of one Transformer layer packed in the order the sample-stationary layer kernel
-        consumes them (include/vct_hip.h, vct_ss_pack), created on first use and rewritten whenever the shadow of that layer is
-        (refresh_transposed: behind the optimizer's pass, inside the recorded step).  blocks_fn() -> [(2-D shadow view, nchunks,
-        first chunk)]."""
+    def want_packed(self, key: str, layers):
+        """(stream, chunks per layer): the weights of a whole Transformer STACK packed, layer after layer, in the order the
+        sample-stationary kernel consumes them (include/vct_hip.h, vct_ss_pack).  layers = [(names, blocks_fn)] per layer, blocks_fn()
+        -> [(2-D shadow view, nchunks, first chunk inside the layer)].  Created on first use; every layer's part is rewritten
+        whenever the shadow of that layer is (refresh_transposed: behind the optimizer's pass, inside the recorded step)."""
         ent = self.packed.get(key)
         if ent is None:
-            blocks = blocks_fn()
-            total = max(dc + nch for _w, nch, dc in blocks)
-            t = torch.empty(total * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
-            a = min(self.offsets[n] for n in names)
-            b = max(self.offsets[n] + self.params[n].numel() for n in names)
-            ent = self.packed[key] = [t, a, b, blocks, total, True]
-        if ent[5]:
-            ops.ss_pack(ent[3], ent[0])
-            ent[5] = False
-        return ent[0], ent[4]
+            per, parts = None, []
+            for names, blocks_fn in layers:
+                blocks = blocks_fn()
+                n = max(dc + nch for _w, nch, dc in blocks)
+                assert per is None or per == n
+                per = n
+                parts.append((names, blocks))
+            t = torch.empty(per * len(parts) * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
+            subs = []
+            for l, (names, blocks) in enumerate(parts):
+                a = min(self.offsets[n] for n in names)
+                b = max(self.offsets[n] + self.params[n].numel() for n in names)
+                subs.append([a, b, [(w, nch, dc + l * per) for w, nch, dc in blocks], True])
+            ent = self.packed[key] = [t, per, subs]
+        for sub in ent[2]:
+            if sub[3]:
+                ops.ss_pack(sub[2], ent[0])
+                sub[3] = False
+        return ent[0], ent[1]
 
     def refresh_lazy_transposed(self):
         """Bring every on-demand transposed copy up to date (decode entry points call this before replaying captured steps,
@@ -177,12 +186,13 @@ class ParamSet:
             if ent[3] and name not in skip and a <= ent[1] and ent[2] <= b:
                 ops.transpose(self.c[name], ent[0])
         for ent in self.packed.values():
-            if ent[2] > a and ent[1] < b:                     # the rewritten range touches this layer
-                if a <= ent[1] and ent[2] <= b:
-                    ops.ss_pack(ent[3], ent[0])
-                    ent[5] = False
-                else:                                         # partly rewritten (no schedule does this): re-pack at the next use
-                    ent[5] = True
+            for sub in ent[2]:
+                if sub[1] > a and sub[0] < b:                 # the rewritten range touches this layer
+                    if a <= sub[0] and sub[1] <= b:
+                        ops.ss_pack(sub[2], ent[0])
+                        sub[3] = False
+                    else:                                     # partly rewritten (no schedule does this): re-pack at the next use
+                        sub[3] = True
 
     def eager_transposed_in(self, a: int, b: int):
         """[(name, tensor, start, end)] of the eager transposed copies whose weight lies inside flat elements [a, b)."""
@@ -511,61 +521,75 @@ class _StackBase:
         return (self.fuse_layers and self.dev.type == "cuda" and c["activation"] in ("gelu", "relu")
                 and ops.layer_ss_supported(self.dt, c["d"], c["nhead"], c["ff"], Lr, Lm))
 
-    def _ss_stream(self, lp: str, cross: bool):
-        """The packed weight stream of layer `lp` (blocks in the kernel's consumption order)."""
-        P, ff = self.pre + lp, self.cfg["ff"]
-        names = [P + "self_attn.in_proj_weight", P + "self_attn.out_proj.weight", P + "linear1.weight", P + "linear2.weight"]
-        if cross:
-            names += [P + "multihead_attn.in_proj_weight", P + "multihead_attn.out_proj.weight"]
+    def _ss_stream(self, lps, cross: bool):
+        """The packed weight stream of the stack's layers `lps` (blocks in the kernel's consumption order, layer after layer)."""
+        ff = self.cfg["ff"]
 
-        def blocks():
-            c, out, at = self.ps.c, [], 0
-            mats = [(c[P + "self_attn.in_proj_weight"], 3), (c[P + "self_attn.out_proj.weight"], 1)]
+        def one(lp):
+            P = self.pre + lp
+            names = [P + "self_attn.in_proj_weight", P + "self_attn.out_proj.weight", P + "linear1.weight", P + "linear2.weight"]
             if cross:
-                mats += [(c[P + "multihead_attn.in_proj_weight"], 3), (c[P + "multihead_attn.out_proj.weight"], 1)]
-            for w, nb in mats:
-                for i in range(nb):
-                    out.append((w[512 * i:512 * (i + 1)], 8, at)); at += 8
-            w1, w2 = c[P + "linear1.weight"], c[P + "linear2.weight"]
-            for j in range(ff // 512):
-                out.append((w1[512 * j:512 * (j + 1)], 8, at)); at += 8
-                out.append((w2[:, 512 * j:512 * (j + 1)], 8, at)); at += 8
-            return out
-        return self.ps.want_packed(P, names, blocks)
+                names += [P + "multihead_attn.in_proj_weight", P + "multihead_attn.out_proj.weight"]
 
-    def _layer_ss(self, b, lp, tag, x, Bn, Lr, site, *, ln_tag, ln_name, mem=None, Lm=0, causal=False, kpm=None, final=None):
-        """Layer `lp` on input x [Bn*Lr, d] in one launch.  ln_tag / ln_name: buffer tag and parameter name of the layer's closing
-        norm ('n2.' / 'norm2.' encoder, 'n3.' / 'norm3.' decoder); final = parameter prefix of the stack-final norm (last layer).
-        Returns (layer output, final-norm output or None)."""
+            def blocks():
+                c, out, at = self.ps.c, [], 0
+                mats = [(c[P + "self_attn.in_proj_weight"], 3), (c[P + "self_attn.out_proj.weight"], 1)]
+                if cross:
+                    mats += [(c[P + "multihead_attn.in_proj_weight"], 3), (c[P + "multihead_attn.out_proj.weight"], 1)]
+                for w, nb in mats:
+                    for i in range(nb):
+                        out.append((w[512 * i:512 * (i + 1)], 8, at)); at += 8
+                # feed-forward, software-pipelined: linear1 block 0 | for j: linear1 block j+1 (its K steps carry chunk j's GELU), linear2 K slice j
+                w1, w2 = c[P + "linear1.weight"], c[P + "linear2.weight"]
+                nj = ff // 512
+                out.append((w1[0:512], 8, at)); at += 8
+                for j in range(nj):
+                    if j + 1 < nj:
+                        out.append((w1[512 * (j + 1):512 * (j + 2)], 8, at)); at += 8
+                    out.append((w2[:, 512 * j:512 * (j + 1)], 8, at)); at += 8
+                return out
+            return names, blocks
+        return self.ps.want_packed(self.pre + lps[0] + f"x{len(lps)}", [one(lp) for lp in lps])
+
+    def _stack_ss(self, b, lps, tags, x, Bn, Lr, sites0, *, ln_tag, ln_name, final, mem=None, Lm=0, causal=False, kpm=None):
+        """The layers `lps` (buffer tags `tags`, dropout site bases `sites0`) on input x [Bn*Lr, d] in ONE launch per four layers.
+        ln_tag / ln_name: buffer tag and parameter name of a layer's closing norm ('n2.' / 'norm2.' encoder, 'n3.' / 'norm3.' decoder);
+        final = parameter prefix of the stack-final norm.  Returns (last layer's output, final-norm output)."""
         d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
         M, cross = Bn * Lr, mem is not None
         f32 = torch.float32
-        wpk, nch = self._ss_stream(lp, cross)
+        wpk, per = self._ss_stream(lps, cross)
+        descs, y, y2 = [], x, None
+        for l, (lp, tag, site) in enumerate(zip(lps, tags, sites0)):
+            b.t[tag + "x"] = y
 
-        def norm(t, name):
-            return (self.F(name + "weight"), self.F(name + "bias"), b.get(t + "y", (M, d), self.dt), b.get(t + "mean", (M,), f32),
-                    b.get(t + "rstd", (M,), f32))
-        sa, st = lp + "self_attn.", tag + "sa."
-        bias = {"qkv": self.F(sa + "in_proj_bias"), "o": self.F(sa + "out_proj.bias"), "l1": self.F(lp + "linear1.bias"),
-                "l2": self.F(lp + "linear2.bias")}
-        kw = {}
-        if cross:
-            ca, ct = lp + "multihead_attn.", tag + "ca."
-            bias.update(cq=self.F(ca + "in_proj_bias")[:d], ckv=self.F(ca + "in_proj_bias")[d:], co=self.F(ca + "out_proj.bias"))
-            kw = dict(cross=(b.get(ct + "q", (M, d), self.dt), b.get(ct + "kv", (Bn * Lm, 2 * d), self.dt), b.get(ct + "o", (M, d), self.dt),
-                             b.get(ct + "a", (M, d), self.dt)),
-                      n2=norm(tag + "n2.", lp + "norm2."), mem=mem, Lm=Lm)
-            sites = (site + 1, site + 2, site + 3, site + 4, site + 5, site + 6)
-        else:
-            sites = (site + 1, site + 2, 0, 0, site + 3, site + 4)
-        nl = norm(tag + ln_tag, lp + ln_name)
-        nf = norm("nf.", final) if final is not None else None
-        ops.layer_ss_fwd(B=Bn, Lr=Lr, x=x, wpk=wpk, nchunks=nch, ff=ff, act=self.cfg["activation"], H=H, bias=bias,
-                         sa=(b.get(st + "qkv", (M, 3 * d), self.dt), b.get(st + "o", (M, d), self.dt), b.get(st + "a", (M, d), self.dt)),
-                         n1=norm(tag + "n1.", lp + "norm1."),
-                         ffn=(b.get(tag + "ff.hpre", (M, ff), self.dt), b.get(tag + "ff.h", (M, ff), self.dt), b.get(tag + "ff.f", (M, d), self.dt)),
-                         n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites, **kw)
-        return nl[2], (nf[2] if nf is not None else None)
+            def norm(t, name):
+                return (self.F(name + "weight"), self.F(name + "bias"), b.get(t + "y", (M, d), self.dt), b.get(t + "mean", (M,), f32),
+                        b.get(t + "rstd", (M,), f32))
+            sa, st = lp + "self_attn.", tag + "sa."
+            bias = {"qkv": self.F(sa + "in_proj_bias"), "o": self.F(sa + "out_proj.bias"), "l1": self.F(lp + "linear1.bias"),
+                    "l2": self.F(lp + "linear2.bias")}
+            kw = {}
+            if cross:
+                ca, ct = lp + "multihead_attn.", tag + "ca."
+                bias.update(cq=self.F(ca + "in_proj_bias")[:d], ckv=self.F(ca + "in_proj_bias")[d:], co=self.F(ca + "out_proj.bias"))
+                kw = dict(cross=(b.get(ct + "q", (M, d), self.dt), b.get(ct + "kv", (Bn * Lm, 2 * d), self.dt), b.get(ct + "o", (M, d), self.dt),
+                                 b.get(ct + "a", (M, d), self.dt)),
+                          n2=norm(tag + "n2.", lp + "norm2."), mem=mem, Lm=Lm)
+                sites = (site + 1, site + 2, site + 3, site + 4, site + 5, site + 6)
+            else:
+                sites = (site + 1, site + 2, 0, 0, site + 3, site + 4)
+            nl = norm(tag + ln_tag, lp + ln_name)
+            nf = norm("nf.", final) if l == len(lps) - 1 else None
+            descs.append(ops.layer_ss_desc(
+                B=Bn, Lr=Lr, x=y, wpk=wpk[l * per * ops.SS_CHUNK:], nchunks=per, ff=ff, act=self.cfg["activation"], H=H, bias=bias,
+                sa=(b.get(st + "qkv", (M, 3 * d), self.dt), b.get(st + "o", (M, d), self.dt), b.get(st + "a", (M, d), self.dt)),
+                n1=norm(tag + "n1.", lp + "norm1."),
+                ffn=(b.get(tag + "ff.hpre", (M, ff), self.dt), b.get(tag + "ff.h", (M, ff), self.dt), b.get(tag + "ff.f", (M, d), self.dt)),
+                n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites, **kw))
+            y, y2 = nl[2], (nf[2] if nf is not None else None)
+        ops.layer_ss_fwd(descs)
+        return y, y2
 
     def _ffn_fwd(self, b, tag, lp, x, site):
         M, d = x.shape
@@ -633,13 +657,10 @@ class EncoderEngine(_StackBase):
             mk = mask if mask.is_contiguous() else mask.contiguous()
             kpm = (mk.view(torch.uint8) if mk.dtype == torch.bool else mk, 1)
         b.t["kpm_used"] = kpm
-        if self._ss_ok(Te, 0):          # one launch per layer (+ the stack-final norm inside the last one)
-            mem = None
-            for l in range(L):
-                lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
-                b.t[tag + "x"] = x
-                x, mem = self._layer_ss(b, lp, tag, x, B, Te, site, ln_tag="n2.", ln_name="norm2.", kpm=kpm,
-                                        final="transformer_encoder.norm." if l == L - 1 else None)
+        if self._ss_ok(Te, 0):          # the whole stack (+ the stack-final norm) in one launch per four layers
+            x, mem = self._stack_ss(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, B, Te,
+                                    [ENC_SITE + 16 * l for l in range(L)], ln_tag="n2.", ln_name="norm2.",
+                                    final="transformer_encoder.norm.", kpm=kpm)
             b.t["x_last"] = x
             return mem
         for l in range(L):
@@ -734,13 +755,11 @@ class DecoderEngine(_StackBase):
         M = Bn * Sd
         prefix, self._prefix = self._prefix, None
         if self._ss_ok(Sd, Te) and prefix is None:
-            x, y = self._embed(b, ids, Sd, M), None
+            x = self._embed(b, ids, Sd, M)
             self._kv_prefetched, self._kv_inplace = None, set()
-            for l in range(L):
-                lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
-                b.t[tag + "x"] = x
-                x, y = self._layer_ss(b, lp, tag, x, Bn, Sd, site, ln_tag="n3.", ln_name="norm3.", mem=mem, Lm=Te, causal=True, kpm=kpm,
-                                      final="decoder.norm." if l == L - 1 else None)
+            x, y = self._stack_ss(b, [f"decoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, Bn, Sd,
+                                  [DEC_SITE + 16 * l for l in range(L)], ln_tag="n3.", ln_name="norm3.", final="decoder.norm.",
+                                  mem=mem, Lm=Te, causal=True, kpm=kpm)
             b.t["x_last"] = x
             return y
         if prefix is not None and prefix[0] is b:        # embedding + bottom self-attention already ran beside the encoder

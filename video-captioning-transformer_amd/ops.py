@@ -222,11 +222,11 @@ def ss_pack(blocks, dst: torch.Tensor):
     return dst
 
 
-def layer_ss_fwd(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, cross=None, n2=None, nf=None, mem=None, Lm=0,
-                 causal=False, key_pad=None, seed=None, p_drop=0.0, sites=(0, 0, 0, 0, 0, 0)):
-    """One whole Transformer layer (include/vct_hip.h, vct_layer_ss_fwd).  bias = dict(qkv, o, [cq, ckv, co], l1, l2) fp32 vectors;
-    sa = (qkv, o, a); cross = (q, kv, o, a); ffn = (hpre, h, f); nX = (gamma, beta, y, mean, rstd); sites = dropout sites
-    (self-attention probabilities, norm1, cross-attention probabilities, norm2, feed-forward, norm3)."""
+def layer_ss_desc(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, cross=None, n2=None, nf=None, mem=None, Lm=0,
+                  causal=False, key_pad=None, seed=None, p_drop=0.0, sites=(0, 0, 0, 0, 0, 0)):
+    """Descriptor of ONE layer of a sample-stationary stack launch (include/vct_hip.h, vct_layer_ss_desc).  bias = dict(qkv, o,
+    [cq, ckv, co], l1, l2) fp32 vectors; sa = (qkv, o, a); cross = (q, kv, o, a); ffn = (hpre, h, f); nX = (gamma, beta, y, mean, rstd);
+    sites = dropout sites (self-attention probabilities, norm1, cross-attention probabilities, norm2, feed-forward, norm3)."""
     q = L.LayerSsDesc()
     q.dtype, q.B, q.L, q.Lm, q.d, q.H, q.ff, q.act = L.BF16, int(B), int(Lr), int(Lm), x.shape[1], int(H), int(ff), L.ACT[act]
     q.last, q.causal = int(nf is not None), int(causal)
@@ -259,7 +259,13 @@ def layer_ss_fwd(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, c
     if seed is not None and p_drop > 0.0:
         q.seed, q.p_drop = seed.data_ptr(), float(p_drop)
     q.site_sa, q.site_n1, q.site_ca, q.site_n2, q.site_ff, q.site_n3 = (int(s) for s in sites)
-    L.check(L.load().vct_layer_ss_fwd(q, L.stream_ptr()), "vct_layer_ss_fwd")
+    return q
+
+
+def layer_ss_fwd(descs):
+    """A whole stack (list of layer_ss_desc results, first layer first) in ceil(n / 4) launches (vct_layer_ss_fwd)."""
+    arr = (L.LayerSsDesc * len(descs))(*descs)
+    L.check(L.load().vct_layer_ss_fwd(arr, len(descs), L.stream_ptr()), "vct_layer_ss_fwd")
 
 
 _ll_ok = {}
