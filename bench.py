@@ -120,6 +120,53 @@ def cpu_baseline():
                       f"(T=12->S=20, V=30522); " + "; ".join(legs) + f"; {spent:.1f} s of timed CPU work", "loss": loss}
 
 
+OTHER_CONFIGS = (("shipped d=768 1+3 T=12 S=20", 768, 1, 3, 12, 20), ("configs[3] d=1024 6+6 T=32 S=40", 1024, 6, 6, 32, 40))
+
+
+def other_configs(device, dtype, peak):
+    """Side lines (untimed w.r.t. the headline value): the same training step -- fwd + bwd + Adam, dropout 0.3, batch 256, recorded launch
+    list -- on the other BASELINE.json shapes: the shipped MSR-VTT config (d=768, 1 enc + 3 dec layers) and configs[3] (d=1024, 6 + 6
+    layers, 32 frames, 40 tokens, head_dim 128).  3 warm-up + 6 timed steps each, HIP events on the step's stream."""
+    import copy
+    from vct_amd.model import MMT4Caption
+    from vct_amd.trainer import CaptionTrainer, build_optimizer
+    out = {}
+    for name, d, Le, Ld, T, S in OTHER_CONFIGS:
+        try:
+            mc = copy.deepcopy(MODEL_CFG)
+            mc["embed_dim"] = d
+            mc["video_encoder"]["layer"], mc["caption_decoder"]["layer"] = Le, Ld
+            torch.manual_seed(666)
+            m = MMT4Caption(mc, device=device, compute_dtype=dtype)
+            m.mode("caption"); m.train()
+            opt, _ = build_optimizer(TRAIN_CFG, m)
+            tr = CaptionTrainer(m, opt, launch_list=True)
+            g = torch.Generator().manual_seed(0)
+            feats = torch.randn(256, T, D_IN, generator=g).to(device)
+            mask = torch.zeros(256, T, dtype=torch.bool, device=device)
+            ids = torch.randint(1000, 30000, (256, S), generator=g); ids[:, 0], ids[:, -1] = 101, 102
+            feats, mask, ids = tr.adopt_inputs(feats, mask, ids.to(device))
+            for _ in range(3):
+                tr.step(feats, mask, ids)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(6):
+                loss = tr.step(feats, mask, ids)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 6
+            fl = algorithmic_flops(256, d=d, ff=2048, Le=Le, Ld=Ld, T=T, S=S)["step"]
+            out[name] = {"ms_per_step": round(ms, 3), "samples_per_s": round(256 / ms * 1e3, 1), "step_tflops": round(fl / ms / 1e9, 1),
+                         "step_frac_of_peak": round(fl / ms / 1e9 / peak, 4), "params_M": round(m.caption_param_end / 1e6, 1),
+                         "loss": round(float(loss), 4)}
+            del m, tr, opt
+            torch.cuda.empty_cache()
+        except Exception as e:          # a side line never takes the headline down with it
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
 def decode_line(device, dtype):
     """configs[4]: greedy decode (KV cache + captured per-token step) of the cfg-B model in eval mode, batch 1 and 128:
     whole-call time per token step (encoder forward, memory K/V projection and host checks included) and the step alone.
@@ -178,6 +225,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="same as --executor graph")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode line (configs[4])")
     ap.add_argument("--no-b1024", action="store_true", help="skip the north_star_b1024 side line (same kernels, per-GPU batch 1024)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the side lines of the shipped d=768 shape and configs[3] (d=1024, 6+6)")
+    ap.add_argument("--comm-cu-mask", type=int, default=0, help="N > 1: confine the communicator's stream (RCCL kernels) to the first N CUs")
     ap.add_argument("--overlap-adam", action="store_true", help="A/B: Adam per gradient bucket on the side stream during backward (measured slower)")
     ap.add_argument("--no-overlap-dw", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-overlap-kv", action="store_true", help="A/B: cross-attention K/V projections and d(memory) GEMMs on the main stream")
@@ -203,6 +252,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.comm_cu_mask > 0:
+        os.environ["VCT_COMM_CU_MASK"] = str(args.comm_cu_mask)      # read by vct_comm_init when it creates the communicator's stream
     device, rank, world = configure_hardware("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -235,7 +286,7 @@ def main():
         opt = torch.optim.Adam([flat], lr=1e-4, betas=(0.9, 0.999), fused=True)
     else:
         opt, _ = build_optimizer(TRAIN_CFG, model)
-    ex, exchange_kind = None, None
+    ex, exchange_kind, rccl_ranks = None, None, None
     if world > 1 or args.force_exchange:
         payload = torch.bfloat16 if args.payload == "bf16" else None
         if args.exchange != "c10d" and not args.torch_adam:
@@ -265,6 +316,7 @@ def main():
                       file=sys.stderr, flush=True)
                 coll = C10dColl()
                 payload = None
+            rccl_ranks = getattr(coll, "lib_world", None)      # what the RCCL communicator itself reports (None: torch.distributed fallback)
             ex = ShardedExchange(model, opt, coll, sharded=args.exchange == "sharded", payload_dtype=payload)
             exchange_kind = f"{args.exchange}/{'vct_comm' if coll.owns_stream else 'c10d'}"
             if os.environ.get("VCT_COMM_IDLE") == "1":      # experiment: the communicator exists but carries nothing
@@ -362,14 +414,19 @@ def main():
         # roofline kernel = the LONGEST of the three equal-FLOP generator GEMMs of the step (picked above, bracketed inside the
         # timed region).  The weight gradient shares the chip with the encoder backward on the second stream, so its bracket is
         # co-scheduled time -- that is what the step pays for it, and what is reported.
-        traffic = None        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
-        traffic_src = None
-        for name in ("r03_roofline_traffic.json", "r02_roofline_traffic.json"):
+        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/): the entry must name the SAME
+        # kernel symbol the tag runs today -- a stale file (the kernel behind a tag changed) yields null, not a wrong number
+        SYMBOL = {"gen_fwd": "gemm256_kernel<0, 1, bf16>", "gen_dx": "gemm256_kernel<0, 1, float>",
+                  "gen_dw": "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"}
+        traffic, traffic_src = None, None
+        for name in ("r04_roofline_traffic.json", "r03_roofline_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if args.batch == 256 and args.dtype == "bf16":
-                    traffic, traffic_src = tj[dom]["hbm_bytes"], f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{name}"
-                break
+                ent = tj[dom]
+                same = ent.get("kernel") is None and name.startswith("r03") or SYMBOL[dom] in str(ent.get("kernel", ""))
+                if args.batch == 256 and args.dtype == "bf16" and same:
+                    traffic, traffic_src = ent["hbm_bytes"], f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of {SYMBOL[dom]}, profiles/{name}"
+                    break
             except Exception:
                 continue
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -432,7 +489,17 @@ def main():
                 "step_ms": round(b1024["step"], 4), "samples_per_s": round(1024 / (b1024["step"] * 1e-3), 1)},
             "hbm_kernels": hbm,
             "loss": final_loss,
+            # data-parallel exchange evidence (null at N = 1): ranks of the RCCL communicator, what the compute stream waits for it at
+            # the end of a step, and how long each gradient bucket occupies the communicator's stream (second, untimed pass)
+            "comm": None if ex is None else {
+                "rccl_ranks": rccl_ranks, "kind": exchange_kind, "cu_mask": args.comm_cu_mask or None,
+                "exposed_wait_ms": round(kern["comm_wait"], 4) if "comm_wait" in kern else None,
+                "bucket_ms_on_comm_stream": [round(kern[f"comm_b{i}"], 4) if f"comm_b{i}" in kern else None
+                                             for i in range(min(8, len(model.grad_buckets())))],
+                "buckets": "generator | decoder layers top-down | token embedding | encoder layers top-down (+ unify)"},
         }
+        if world == 1 and args.batch == 256 and not args.no_other_configs:
+            out["other_configs"] = other_configs(device, model.compute_dtype, peak)
         if world == 1 and not args.no_decode:
             out["decode"] = decode_line(device, model.compute_dtype)
         if world == 1 and not args.no_cpu_baseline:

@@ -210,7 +210,8 @@ int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
  *   x bf16 [B*L, 512] layer input; mem bf16 [B*Lm, 512] (decoder layers; NULL = encoder layer: no cross-attention block,
  *   n2 unused).  Self-attention masks as vct_attn_desc (causal; key_pad + key_pad_shift; key_ids / pad_id).
  *   wpk: the layer's weights packed in STREAM ORDER by vct_ss_pack -- 64-KiB chunks (one 512-row block x 64 K columns of a
- *   weight, as 8 waves x 8 MFMA fragments of 1 KiB), blocks in consumption order:
+ *   weight, as 8 waves x 8 MFMA fragments of 1 KiB: wave w, column tile t < 4, k-step s < 2 = rows 64w + 16t .. +15,
+ *   columns 32s .. 32s + 31 of the chunk), blocks in consumption order:
  *     in_proj rows [0,512) [512,1024) [1024,1536) | out_proj | (decoder: cross in_proj rows [0,512) | [512,1024) [1024,1536) |
  *     cross out_proj) | linear1 rows [0,512) | for j < ff/512: linear1 rows [512(j+1), 512(j+2)) (while j+1 < ff/512) ,
  *     linear2 columns [512j, 512j+512)        (the feed-forward block is software-pipelined: the GELU / dropout of chunk j is

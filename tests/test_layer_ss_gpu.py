@@ -80,7 +80,7 @@ def test_fused_forward_vs_oracle(shape, act):
     ref_loss, ref_grads, ref_logits = O.caption_loss_and_grads(p, cfg, f, mk, ids)
     m = build_model(mc, V, DEV, BF, p)
     m.train()
-    assert m.cap_decoder._engine()._ss_ok(S - 1, T + 1) and m.video_encoder._engine()._ss_ok(T + 1, 0)
+    assert m.cap_decoder._engine()._ss_ok(S - 1, T + 1, B) and m.video_encoder._engine()._ss_ok(T + 1, 0, B)
     feats, mask, idt = (torch.from_numpy(a).to(DEV) for a in (f, mk, ids))
     loss, logits = m._forward_loss(feats, mask, idt, True, want_logits=True)
     assert abs(float(loss) - ref_loss) < 1e-3 * abs(ref_loss), (float(loss), ref_loss)

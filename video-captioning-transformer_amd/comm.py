@@ -40,6 +40,8 @@ class C10dColl:
                 torch.cuda.synchronize(t.device)
             ops.host_call(at_replay)
         else:
+            if t.is_cuda:      # host-side collective on device buffers: everything enqueued so far on this stream has to be done
+                torch.cuda.current_stream(t.device).synchronize()
             fn()
 
     def allreduce_avg(self, t, after=None):
@@ -94,6 +96,7 @@ class RcclColl:
         s = L.vp()
         L.check(lib.vct_comm_stream(h, C.byref(s)), "vct_comm_stream")
         self.stream = torch.cuda.ExternalStream(s.value, device=device)
+        self.lib_world = int(lib.vct_comm_world(h))          # ranks the RCCL communicator itself reports
 
     @staticmethod
     def _after(after):

@@ -107,8 +107,17 @@ extern "C" int vct_comm_init(const uint8_t* id128, int rank, int world, void** o
   // slowed the compute streams' kernels by 10 %, and with collectives in flight on it every kernel of the step ran 2-3.5x
   // slower (step 2.65 -> 7.7 ms at world size 1); VCT_COMM_PRIO=1 re-enables it for experiments.
   static const char* prio_env = getenv("VCT_COMM_PRIO");
+  // VCT_COMM_CU_MASK=N (bench.py --comm-cu-mask N): confine the collectives' kernels to the first N CUs (hipExtStreamCreateWithCUMask;
+  // only "first N" masks take effect on this runtime, tools/cu_mask_probe2.py) so that RCCL cannot spread over the compute
+  // streams' CUs.  Unmeasured at N > 1 ranks (1-GPU boxes): an experiment switch for the driver's scaling run.
+  const char* mask_env = getenv("VCT_COMM_CU_MASK");
+  const int mask_n = mask_env != nullptr ? atoi(mask_env) : 0;
   hipError_t e;
-  if (prio_env != nullptr && prio_env[0] == '1') {
+  if (mask_n > 0 && mask_n < 256) {
+    uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int cu = 0; cu < mask_n; cu++) words[cu >> 5] |= 1u << (cu & 31);
+    e = hipExtStreamCreateWithCUMask(&c->stream, 8, words);
+  } else if (prio_env != nullptr && prio_env[0] == '1') {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);

@@ -33,7 +33,15 @@
 
 namespace vct {
 
-constexpr int SS_D = 512, SS_H = 8, SS_HD = 64, SS_NW = 8, SS_NT = 512;
+constexpr int SS_D = 512, SS_H = 8, SS_HD = 64;
+// Waves per workgroup: 8 (2 per SIMD, <= 256 registers) or 16 (4 per SIMD, <= 128 registers, a wave owns 32 columns per block).
+// Measured at cfg-B (tools/ss_layer_stamps.hip, gpurun_out/r4f vs r4g): 16 waves finish a product block faster per wave (7-8.5 k
+// cycles vs 8-9.5 k) but pay it back at every barrier (wave 0 waits 6-15 k cycles for the other fifteen after multi-block
+// products) and spill in the LayerNorm epilogues: decoder layer 140 us either way, encoder layer 87 vs 81 us -> 8 waves.
+constexpr int SS_NW = 8, SS_NT = SS_NW * 64;
+constexpr int SS_TPW = 32 / SS_NW;                 // 16-column MFMA tiles per wave and 512-column block
+constexpr int SS_CPW = SS_TPW * 16;                // columns per wave and block
+constexpr int SS_WSTR = SS_TPW * 2 * 512;          // bf16 elements of a chunk that belong to one wave (SS_TPW tiles x 2 k-steps x 1 KiB)
 constexpr int SS_PSTR = SS_D + 8;                  // row stride (bf16 elements) of a [32][512] panel
 constexpr int SS_SLOT = 32 * SS_PSTR * 2;          // 33,280 B
 constexpr int SS_QSTR = 3 * SS_D + 8;              // q | k | v panel (self-attention): 32 x 1544 bf16 = 3 slots
@@ -43,8 +51,7 @@ constexpr int SS_RM = 4 * SS_SLOT;                 // memory rows of this sample
 constexpr int SS_RED = SS_RM + 16 * SS_PSTR * 2;   // LayerNorm partials: 2 x [8 waves][32 rows] fp32
 constexpr int SS_B1 = SS_RED + 2 * SS_NW * 32 * 4;   // linear1 bias (fp32, ff <= 2048): read by the pipelined feed-forward epilogue
 constexpr int SS_FF_MAX = 2048;
-constexpr int SS_B2 = SS_B1 + SS_FF_MAX * 4;           // linear2 bias (fp32, 512)
-constexpr int SS_LDS = SS_B2 + SS_D * 4;
+constexpr int SS_LDS = SS_B1 + SS_FF_MAX * 4;
 constexpr long SS_CHUNK = 32768;                   // bf16 elements per K chunk of the stream (64 KiB: 8 waves x 8 fragments x 1 KiB)
 static_assert(SS_LDS <= 160 * 1024, "LDS budget");
 static_assert(32 * SS_QSTR * 2 <= 3 * SS_SLOT && 16 * SS_KVSTR * 2 <= SS_SLOT, "panel slots");
@@ -100,15 +107,15 @@ __device__ __forceinline__ void ss_barrier() {
 }
 
 // ---- weight stream: this lane's view of the layer's packed weights ------------------------------------------------------------------
-// chunk c of the stream = elements [c*32768, (c+1)*32768): wave w's 8 fragments (column tile t, k-step s) at w*4096 + (t*2+s)*512,
+// chunk c of the stream = elements [c*32768, (c+1)*32768): wave w's 2*SS_TPW fragments (column tile t, k-step s) at w*SS_WSTR + (t*2+s)*512,
 // lane l's 8 bf16 at + l*8.  Loads are UNCONDITIONAL (the pointer stops at the last chunk): straight-line code, exact vmcnt waits.
 struct WStream {
   const bf16_t* p;        // next chunk to fetch (this lane)
   const bf16_t* last;     // last chunk of the layer (this lane)
 };
-__device__ __forceinline__ void ws_fetch(WStream& ws, bf16x8 (&dst)[4][2]) {
+__device__ __forceinline__ void ws_fetch(WStream& ws, bf16x8 (&dst)[SS_TPW][2]) {
 #pragma unroll
-  for (int t = 0; t < 4; t++)
+  for (int t = 0; t < SS_TPW; t++)
 #pragma unroll
     for (int s = 0; s < 2; s++) dst[t][s] = *reinterpret_cast<const bf16x8*>(ws.p + (t * 2 + s) * 512);
   ws.p = (ws.p + SS_CHUNK <= ws.last) ? ws.p + SS_CHUNK : ws.last;
@@ -119,7 +126,7 @@ __device__ __forceinline__ void ws_fetch(WStream& ws, bf16x8 (&dst)[4][2]) {
 // entry b0 / b1 hold the first two chunks (in flight), each buffer is re-fetched right behind the MFMAs that read it, and on exit they
 // hold the first two chunks of whatever comes next in the stream -- so an epilogue between two products has 16 KB per wave in flight.
 template <int MT>
-__device__ __forceinline__ void gemm_step(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc, const bf16x8 (&b)[4][2]) {
+__device__ __forceinline__ void gemm_step(f32x4 (&acc)[MT][SS_TPW], const bf16_t* a, const int astr, const int kc, const bf16x8 (&b)[SS_TPW][2]) {
   bf16x8 af[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; m++)
@@ -130,11 +137,11 @@ __device__ __forceinline__ void gemm_step(f32x4 (&acc)[MT][4], const bf16_t* a, 
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t][s], af[m][s], acc[m][t], 0, 0, 0);
+      for (int t = 0; t < SS_TPW; t++) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t][s], af[m][s], acc[m][t], 0, 0, 0);
 }
 template <int MT>
-__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, const int kc0, const int nch, WStream& ws,
-                                          bf16x8 (&b0)[4][2], bf16x8 (&b1)[4][2]) {
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][SS_TPW], const bf16_t* a, const int astr, const int kc0, const int nch, WStream& ws,
+                                          bf16x8 (&b0)[SS_TPW][2], bf16x8 (&b1)[SS_TPW][2]) {
   for (int c = 0; c < nch; c += 2) {
     gemm_step<MT>(acc, a, astr, kc0 + c, b0);
     ws_fetch(ws, b0);
@@ -144,8 +151,8 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][4], const bf16_t* a, 
 }
 // the same for exactly 8 chunks, fully unrolled, with cb(k) (k = 0..7: independent vector work) issued in front of K step k
 template <int MT, class F>
-__device__ __forceinline__ void wave_gemm8_cb(f32x4 (&acc)[MT][4], const bf16_t* a, const int astr, WStream& ws, bf16x8 (&b0)[4][2],
-                                              bf16x8 (&b1)[4][2], F&& cb) {
+__device__ __forceinline__ void wave_gemm8_cb(f32x4 (&acc)[MT][SS_TPW], const bf16_t* a, const int astr, WStream& ws, bf16x8 (&b0)[SS_TPW][2],
+                                              bf16x8 (&b1)[SS_TPW][2], F&& cb) {
   static_for<4>([&](auto I) {
     constexpr int i = decltype(I)::value;
     cb(std::integral_constant<int, 2 * i>{});
@@ -157,16 +164,16 @@ __device__ __forceinline__ void wave_gemm8_cb(f32x4 (&acc)[MT][4], const bf16_t*
   });
 }
 
-template <int MT> __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][4]) {
+template <int MT> __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT][SS_TPW]) {
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[m][t] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < SS_TPW; t++) acc[m][t] = f32x4{0, 0, 0, 0};
 }
 
-__device__ __forceinline__ void load_bias4(float4 (&bv)[4], const float* bias, const int col0, const int lg) {
+__device__ __forceinline__ void load_bias4(float4 (&bv)[SS_TPW], const float* bias, const int col0, const int lg) {
 #pragma unroll
-  for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const float4*>(bias + col0 + t * 16 + lg * 4);
+  for (int t = 0; t < SS_TPW; t++) bv[t] = *reinterpret_cast<const float4*>(bias + col0 + t * 16 + lg * 4);
 }
 
 struct alignas(8) BV4 { bf16_t e[4]; };
@@ -199,9 +206,9 @@ __device__ __forceinline__ void global_to_panel(bf16_t* panel, const int pstr, c
   }
 }
 
-__device__ __forceinline__ void load_gb(float4 (&gm)[4], float4 (&bt)[4], const SsNorm& n, const int ecol) {
+__device__ __forceinline__ void load_gb(float4 (&gm)[SS_TPW], float4 (&bt)[SS_TPW], const SsNorm& n, const int ecol) {
 #pragma unroll
-  for (int t = 0; t < 4; t++) {
+  for (int t = 0; t < SS_TPW; t++) {
     gm[t] = *reinterpret_cast<const float4*>(n.g + ecol + t * 16);
     bt[t] = *reinterpret_cast<const float4*>(n.b + ecol + t * 16);
   }
@@ -209,12 +216,12 @@ __device__ __forceinline__ void load_gb(float4 (&gm)[4], float4 (&bt)[4], const 
 
 // plain epilogue: panel[row][pcol0 + ...] = bf16(acc + bias)
 template <int MT>
-__device__ __forceinline__ void epi_store(const f32x4 (&acc)[MT][4], const float4 (&bv)[4], bf16_t* panel, const int pstr, const int pcol0,
+__device__ __forceinline__ void epi_store(const f32x4 (&acc)[MT][SS_TPW], const float4 (&bv)[SS_TPW], bf16_t* panel, const int pstr, const int pcol0,
                                           const int li, const int lg) {
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < SS_TPW; t++) {
       BV4 o;
       o.e[0] = f2bf(acc[m][t][0] + bv[t].x); o.e[1] = f2bf(acc[m][t][1] + bv[t].y);
       o.e[2] = f2bf(acc[m][t][2] + bv[t].z); o.e[3] = f2bf(acc[m][t][3] + bv[t].w);
@@ -226,13 +233,17 @@ __device__ __forceinline__ void epi_store(const f32x4 (&acc)[MT][4], const float
 //   a = bf16(acc + bias) -> panel AP;  s = a * dropmask + res;  y = LN(s) -> panel YP;  [y2 = LN2(bf16 y) -> panel Y2P]
 // res: 4 bf16 per (m, t) in registers.  Row statistics: this wave's 64 columns -> 4-lane-group shuffle -> LDS partials of the 8 waves.
 template <int MT>
-__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4], const BV4 (&res)[MT][4], const SsNorm& n, const SsNorm* n2,
+__device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][SS_TPW], const float4 (&bv)[SS_TPW], const BV4 (&res)[MT][SS_TPW], const SsNorm& n, const SsNorm* n2,
                                        const Dropout& dr, const long grow0, const int L, bf16_t* AP, bf16_t* YP, bf16_t* Y2P, float* red,
-                                       const int wave, const int li, const int lg) {
-  const int colw = wave * 64 + lg * 4;
+                                       const int wave, const int li_in, const int lg_in) {
+  // lane indices behind an opaque barrier: otherwise the address / counter arithmetic shared by the layer's three LayerNorm
+  // epilogues is computed once and kept alive (spilled) from the first to the last of them
+  int li = li_in, lg = lg_in;
+  asm volatile("" : "+v"(li), "+v"(lg));
+  const int colw = wave * SS_CPW + lg * 4;
   // gamma / beta: issued now, first used two barriers further down -- they land behind the 16 KB of weight prefetch this wave has in
   // flight (in-order return) without anybody waiting for them
-  float4 gm[4], bt[4];
+  float4 gm[SS_TPW], bt[SS_TPW];
   load_gb(gm, bt, n, colw);
   float part[MT];
 #pragma unroll
@@ -240,7 +251,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
     part[m] = 0.0f;
     const uint32_t grow = (uint32_t)(grow0 + m * 16 + li);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < SS_TPW; t++) {
       const float bb[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
       float dm[4];
       drop_mults<4>(dr, grow * (uint32_t)SS_D + (uint32_t)(colw + t * 16), dm);
@@ -273,7 +284,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
       mean[m] = s * (1.0f / (float)SS_D);
       sq[m] = 0.0f;
 #pragma unroll
-      for (int t = 0; t < 4; t++)
+      for (int t = 0; t < SS_TPW; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) { const float c = acc[m][t][r] - mean[m]; sq[m] += c * c; }
       sq[m] = red4_sum(sq[m]);
@@ -302,7 +313,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
   for (int m = 0; m < MT; m++) {
     part[m] = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < SS_TPW; t++) {
       const float gg[4] = {gm[t].x, gm[t].y, gm[t].z, gm[t].w}, be[4] = {bt[t].x, bt[t].y, bt[t].z, bt[t].w};
       BV4 yv;
 #pragma unroll
@@ -317,7 +328,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
   }
   if (n2 != nullptr) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < SS_TPW; t++) {
       gm[t] = *reinterpret_cast<const float4*>(n2->g + colw + t * 16);
       bt[t] = *reinterpret_cast<const float4*>(n2->b + colw + t * 16);
     }
@@ -330,7 +341,7 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][4], const float4 (&bv)[4
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < SS_TPW; t++) {
         const float gg[4] = {gm[t].x, gm[t].y, gm[t].z, gm[t].w}, be[4] = {bt[t].x, bt[t].y, bt[t].z, bt[t].w};
         BV4 yv;
 #pragma unroll
@@ -354,11 +365,11 @@ __device__ __forceinline__ bf16x8 ss_frag_colk(const bf16_t* p, const int str, c
 }
 __device__ __forceinline__ void ss_attn_wave(const bf16_t* Qp, const int strq, const bf16_t* Kp, const bf16_t* Vp, const int strkv, const int Lq,
                                              const int Lk, const int causal, const unsigned long long padmask, const Dropout& dr, const int bh,
-                                             bf16_t* OPh, const int lane) {
+                                             bf16_t* OPh, const int lane, const int qt0, const int qstep) {
   const int i = lane & 15, g = lane >> 4;
   const int LQT = (Lq + 15) >> 4, LKT = (Lk + 15) >> 4;     // <= 2 each
   const float scale = 0.125f;                                // 1 / sqrt(64)
-  for (int qt = 0; qt < LQT; qt++) {
+  for (int qt = qt0; qt < LQT; qt += qstep) {        // query tiles qt0, qt0 + qstep, ...: the waves that share a head split them
     f32x4 st[2];
     const int qq = qt * 16 + i;
 #pragma unroll
@@ -431,7 +442,7 @@ __device__ __forceinline__ unsigned long long ss_padmask(const SsLayerP& p, cons
 }
 
 template <bool CROSS, int MT>
-__global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p) {
+__global__ __launch_bounds__(SS_NT, SS_NW / 4) void layer_ss_fwd_kernel(const SsLayerP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -444,18 +455,19 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
   bf16_t* RMp = reinterpret_cast<bf16_t*>(smem + SS_RM);
   float* red = reinterpret_cast<float*>(smem + SS_RED);
   float* b1s = reinterpret_cast<float*>(smem + SS_B1);
-  float* b2s = reinterpret_cast<float*>(smem + SS_B2);
 
   WStream ws;
-  ws.p = p.wpk + (long)wave * 4096 + lane0 * 8;
+  ws.p = p.wpk + (long)wave * SS_WSTR + lane0 * 8;
   ws.last = ws.p + (long)(p.nchunks - 1) * SS_CHUNK;
-  bf16x8 b0[4][2], b1[4][2];
+  bf16x8 b0[SS_TPW][2], b1[SS_TPW][2];
   ws_fetch(ws, b0);                                        // the stream starts before the first activation byte is here,
   ws_fetch(ws, b1);                                        // two chunks ahead: both buffers are in flight between products
 
   global_to_panel(R0, SS_PSTR, L, MT * 16, p.x, SS_D, grow0, tid0);
   if constexpr (CROSS) global_to_panel(RMp, SS_PSTR, p.Lm, 16, p.mem, SS_D, (long)b * p.Lm, tid0);
   const unsigned long long padmask = ss_padmask(p, b, lane0);
+  constexpr int SS_WPH = SS_NW / SS_H;                     // waves per attention head: they take the query tiles in turn
+  const int head = wave / SS_WPH, qt0 = wave % SS_WPH, hd0 = head * SS_HD;
   // panels of the feed-forward phase (slot plan: DESIGN.md): input rows, the two activation buffers, f, y (= the next layer's x), y2
   bf16_t* FIN = CROSS ? R0 : R1B;
   bf16_t* HP0 = CROSS ? R1B : R0;
@@ -475,32 +487,31 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int aoff = li * SS_PSTR + lg * 8;                // this lane's A-fragment origin inside a [32][SS_PSTR] panel
-    const int ecol = wave * 64 + lg * 4;                   // this lane's first epilogue column inside a 512-column block (+ t*16)
+    const int ecol = wave * SS_CPW + lg * 4;                   // this lane's first epilogue column inside a 512-column block (+ t*16)
     const __attribute__((address_space(4))) SsLayerW& w = kp->lw[l];     // fields are fetched (scalar loads) where they are used
     auto nrm = [](const __attribute__((address_space(4))) SsNorm& n) { return SsNorm{n.g, n.b, n.y, n.mean, n.rstd}; };
     const bool fin = p.last && l == p.nl - 1;
     // the layer's linear1 bias -> LDS (the x panel of layers l > 0 is already in R0: the previous layer's output)
     for (int v = tid; v < (p.ff >> 2); v += SS_NT) reinterpret_cast<float4*>(b1s)[v] = reinterpret_cast<const float4*>(w.b1)[v];
-    if (tid < SS_D / 4) reinterpret_cast<float4*>(b2s)[tid] = reinterpret_cast<const float4*>(w.b2)[tid];
     SS_STAMP(0);
     ss_barrier();
     SS_STAMP(1);
 
-    f32x4 acc[MT][4];
-    float4 bv[4];
+    f32x4 acc[MT][SS_TPW];
+    float4 bv[SS_TPW];
     // ---- self-attention block --------------------------------------------------------------------------------------------------------
     for (int nb = 0; nb < 3; nb++) {                       // q | k | v = x W_in^T + b_in  -> panel [32][1544] in R1A..R1C
-      load_bias4(bv, w.b_qkv, nb * 512 + wave * 64, lg);
+      load_bias4(bv, w.b_qkv, nb * 512 + wave * SS_CPW, lg);
       acc_zero<MT>(acc);
       wave_gemm<MT>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-      epi_store<MT>(acc, bv, R1A, SS_QSTR, nb * 512 + wave * 64, li, lg);
+      epi_store<MT>(acc, bv, R1A, SS_QSTR, nb * 512 + wave * SS_CPW, li, lg);
     }
     // residual rows of the out_proj epilogue: out of the x panel, which is about to become the attention output panel
-    BV4 res[MT][4];
+    BV4 res[MT][SS_TPW];
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R0 + (m * 16 + li) * SS_PSTR + ecol + t * 16);
+      for (int t = 0; t < SS_TPW; t++) res[m][t] = *reinterpret_cast<const BV4*>(R0 + (m * 16 + li) * SS_PSTR + ecol + t * 16);
     SS_STAMP(2);
     ss_barrier();
     SS_STAMP(3);
@@ -508,8 +519,8 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     SS_STAMP(4);
     {
       const Dropout dr = make_dropout(p.seed, w.site_sa, p.p_drop);
-      ss_attn_wave(R1A + wave * 64, SS_QSTR, R1A + SS_D + wave * 64, R1A + 2 * SS_D + wave * 64, SS_QSTR, L, L, p.causal, padmask, dr,
-                   b * SS_H + wave, R0 + wave * 64, lane);
+      ss_attn_wave(R1A + hd0, SS_QSTR, R1A + SS_D + hd0, R1A + 2 * SS_D + hd0, SS_QSTR, L, L, p.causal, padmask, dr,
+                   b * SS_H + head, R0 + hd0, lane, qt0, SS_WPH);
     }
     SS_STAMP(5);
     ss_barrier();
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     panel_to_global<SS_D>(R0, SS_PSTR, L, w.o, SS_D, grow0, 0, tid);
     SS_STAMP(7);
     {                                                      // a = o W_o^T + b_o;  x1 = LN1(x + drop(a))
-      load_bias4(bv, w.b_o, wave * 64, lg);
+      load_bias4(bv, w.b_o, wave * SS_CPW, lg);
       acc_zero<MT>(acc);
       wave_gemm<MT>(acc, R0 + aoff, SS_PSTR, 0, 8, ws, b0, b1);
       SS_STAMP(8);
@@ -533,17 +544,17 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     if constexpr (CROSS) {
       // ---- cross-attention block -----------------------------------------------------------------------------------------------------
       const int Lm = p.Lm;
-      load_bias4(bv, w.b_cq, wave * 64, lg);               // q = x1 W_q^T + b_q -> R1C
+      load_bias4(bv, w.b_cq, wave * SS_CPW, lg);               // q = x1 W_q^T + b_q -> R1C
       acc_zero<MT>(acc);
       wave_gemm<MT>(acc, R1B + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-      epi_store<MT>(acc, bv, R1C, SS_PSTR, wave * 64, li, lg);
+      epi_store<MT>(acc, bv, R1C, SS_PSTR, wave * SS_CPW, li, lg);
       SS_STAMP(11);
       for (int nb = 0; nb < 2; nb++) {                     // k | v = mem W_kv^T + b_kv -> panel [16][1032] in R0
-        f32x4 acm[1][4];
-        load_bias4(bv, w.b_ckv, nb * 512 + wave * 64, lg);
+        f32x4 acm[1][SS_TPW];
+        load_bias4(bv, w.b_ckv, nb * 512 + wave * SS_CPW, lg);
         acc_zero<1>(acm);
         wave_gemm<1>(acm, RMp + aoff, SS_PSTR, 0, 8, ws, b0, b1);
-        epi_store<1>(acm, bv, R0, SS_KVSTR, nb * 512 + wave * 64, li, lg);
+        epi_store<1>(acm, bv, R0, SS_KVSTR, nb * 512 + wave * SS_CPW, li, lg);
       }
       SS_STAMP(12);
       ss_barrier();
@@ -553,8 +564,8 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
       {
         const Dropout dr = make_dropout(p.seed, w.site_ca, p.p_drop);
         // rows >= Lm of the 16-row k | v panel: computed from zero memory rows = the bias, finite
-        ss_attn_wave(R1C + wave * 64, SS_PSTR, R0 + wave * 64, R0 + SS_D + wave * 64, SS_KVSTR, L, Lm, 0, 0ull, dr, b * SS_H + wave,
-                     R1A + wave * 64, lane);
+        ss_attn_wave(R1C + hd0, SS_PSTR, R0 + hd0, R0 + SS_D + hd0, SS_KVSTR, L, Lm, 0, 0ull, dr, b * SS_H + head,
+                     R1A + hd0, lane, qt0, SS_WPH);
       }
       SS_STAMP(14);
       ss_barrier();
@@ -564,8 +575,8 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
-          for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(R1B + (m * 16 + li) * SS_PSTR + ecol + t * 16);
-        load_bias4(bv, w.b_co, wave * 64, lg);
+          for (int t = 0; t < SS_TPW; t++) res[m][t] = *reinterpret_cast<const BV4*>(R1B + (m * 16 + li) * SS_PSTR + ecol + t * 16);
+        load_bias4(bv, w.b_co, wave * SS_CPW, lg);
         acc_zero<MT>(acc);
         wave_gemm<MT>(acc, R1A + aoff, SS_PSTR, 0, 8, ws, b0, b1);
         SS_STAMP(16);
@@ -584,8 +595,8 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     // The epilogue of a chunk is ~9 k cycles of vector ALU work that nothing else in the workgroup could overlap; issued between the
     // K steps of the NEXT chunk's linear1 it runs in the shadow of that product's weight stream.  The activation panel is double-
     // buffered (one barrier per chunk); the pre-activation goes to HBM straight from the registers (8-byte stores).
-    f32x4 facc[MT][4];
-    BV4 hpk[MT][4];                                          // pre-activation of the chunk whose epilogue is pending, as stored (bf16)
+    f32x4 facc[MT][SS_TPW];
+    BV4 hpk[MT][SS_TPW];                                          // pre-activation of the chunk whose epilogue is pending, as stored (bf16)
     acc_zero<MT>(facc);
     const Dropout drf = make_dropout(p.seed, w.site_ff, p.p_drop);
     const int nj = p.ff >> 9;
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
 #pragma unroll
       for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < SS_TPW; t++) {
           const int row = m * 16 + li, col = j * 512 + ecol + t * 16;
           const float4 bb = *reinterpret_cast<const float4*>(b1s + col);
           BV4 pv;
@@ -605,8 +616,8 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
     };
     auto ffn_tile = [&](const int j, auto K) {               // GELU + dropout of ONE 16 x 16 tile of chunk j -> activation panel
       constexpr int k = decltype(K)::value;
-      if constexpr (k < MT * 4) {
-        constexpr int m = k / 4, t = k % 4;
+      if constexpr (k < MT * SS_TPW) {
+        constexpr int m = k / SS_TPW, t = k % SS_TPW;
         const int row = m * 16 + li;
         const int col = j * 512 + ecol + t * 16;
         float dm[4];
@@ -619,6 +630,7 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
         *reinterpret_cast<BV4*>(((j & 1) ? HP1 : HP0) + row * SS_PSTR + ecol + t * 16) = hv;
       }
     };
+    load_bias4(bv, w.b2, wave * SS_CPW, lg);             // linear2's bias: 2 float4 that ride through the chunk loop (issued here, ahead of the stream)
     acc_zero<MT>(acc);
     wave_gemm<MT>(acc, FIN + aoff, SS_PSTR, 0, 8, ws, b0, b1);
     ffn_pre(0);
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
         acc_zero<MT>(acc);
         wave_gemm8_cb<MT>(acc, FIN + aoff, SS_PSTR, ws, b0, b1, [&](auto K) { ffn_tile(j, K); });
       } else {
-        static_for<MT * 4>([&](auto K) { ffn_tile(j, K); });
+        static_for<MT * SS_TPW>([&](auto K) { ffn_tile(j, K); });
       }
       SS_STAMP(21 + 4 * j);
       ss_barrier();
@@ -643,8 +655,7 @@ __global__ __launch_bounds__(SS_NT, 2) void layer_ss_fwd_kernel(const SsLayerP p
 #pragma unroll
       for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) res[m][t] = *reinterpret_cast<const BV4*>(FIN + (m * 16 + li) * SS_PSTR + ecol + t * 16);
-      load_bias4(bv, b2s, wave * 64, lg);
+        for (int t = 0; t < SS_TPW; t++) res[m][t] = *reinterpret_cast<const BV4*>(FIN + (m * 16 + li) * SS_PSTR + ecol + t * 16);
       ss_barrier();                                        // the last chunk's copy and linear2 reads are done: the activation buffers become y / y2
       const Dropout dr = make_dropout(p.seed, w.site_n3, p.p_drop);
       const SsNorm nfl = p.nf;                             // (a pointer into the by-value argument would put all of it into scratch)
@@ -672,10 +683,11 @@ __global__ __launch_bounds__(256) void ss_pack_kernel(const SsPackP p) {
   const SsPackSeg s = p.seg[sg];
   const long v = (long)blockIdx.x * 256 + threadIdx.x;     // vector index inside the segment
   if (v >= (long)s.nchunks * (SS_CHUNK / 8)) return;
-  const int lane = (int)(v & 63), frag = (int)((v >> 6) & 7), w = (int)((v >> 9) & 7);
+  constexpr int FPW = 2 * SS_TPW;                            // fragments per wave and chunk
+  const int lane = (int)(v & 63), frag = (int)((v >> 6) % FPW), w = (int)((v >> 6) / FPW % SS_NW);
   const long c = v >> 12;
   const int t = frag >> 1, ks = frag & 1;
-  const int n = w * 64 + t * 16 + (lane & 15);
+  const int n = w * SS_CPW + t * 16 + (lane & 15);
   const long k = c * 64 + ks * 32 + (lane >> 4) * 8;
   *reinterpret_cast<BV8s*>(p.dst + ((long)s.dst_chunk + c) * SS_CHUNK + (v & 4095) * 8) = *reinterpret_cast<const BV8s*>(s.w + (long)n * s.ldw + k);
 }

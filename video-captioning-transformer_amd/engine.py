@@ -26,6 +26,16 @@ ENC_SITE, DEC_SITE, EMB_SITE = 0, 1000, 999
 DMEM_SYNC = 0      # named sync point (ops.sync_record / sync_wait): d(memory) is final on the main stream
 
 
+_CUS = {}
+
+
+def _cu_count(dev) -> int:
+    n = _CUS.get(dev)
+    if n is None:
+        n = _CUS[dev] = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 0
+    return n
+
+
 class StepContext:
     """Per-model execution state shared by the engines of ONE parameter set: the side HIP stream (+ its split-K scratch) that
     weight-gradient GEMMs / the encoder backward / the decoder prefix run on, and the buffer generation counter that
@@ -516,10 +526,16 @@ class _StackBase:
     # It saves the tensors and draws the dropout streams of the unfused kernels: the backward schedule is unchanged behind it.
     fuse_layers = os.environ.get("VCT_FUSE_LAYERS", "1") != "0"
 
-    def _ss_ok(self, Lr: int, Lm: int) -> bool:
+    def _ss_ok(self, Lr: int, Lm: int, Bn: int) -> bool:
+        """One workgroup per sample streams ALL of a layer's weights: it pays while the samples fit the CUs in one round (cfg-B:
+        256 samples on 256 CUs, forward bracket 0.52 vs 0.55 ms unfused); at a per-GPU batch of 1024 the tiled GEMMs amortise the
+        weights over 4864+ rows and win (1.39 vs 1.84 ms)."""
         c = self.cfg
-        return (self.fuse_layers and self.dev.type == "cuda" and c["activation"] in ("gelu", "relu")
-                and ops.layer_ss_supported(self.dt, c["d"], c["nhead"], c["ff"], Lr, Lm))
+        if not (self.fuse_layers and self.dev.type == "cuda" and c["activation"] in ("gelu", "relu")):
+            return False
+        if Bn > _cu_count(self.dev) * 5 // 4:
+            return False
+        return ops.layer_ss_supported(self.dt, c["d"], c["nhead"], c["ff"], Lr, Lm)
 
     def _ss_stream(self, lps, cross: bool):
         """The packed weight stream of the stack's layers `lps` (blocks in the kernel's consumption order, layer after layer)."""
@@ -657,7 +673,7 @@ class EncoderEngine(_StackBase):
             mk = mask if mask.is_contiguous() else mask.contiguous()
             kpm = (mk.view(torch.uint8) if mk.dtype == torch.bool else mk, 1)
         b.t["kpm_used"] = kpm
-        if self._ss_ok(Te, 0):          # the whole stack (+ the stack-final norm) in one launch per four layers
+        if self._ss_ok(Te, 0, B):       # the whole stack (+ the stack-final norm) in one launch per four layers
             x, mem = self._stack_ss(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, B, Te,
                                     [ENC_SITE + 16 * l for l in range(L)], ln_tag="n2.", ln_name="norm2.",
                                     final="transformer_encoder.norm.", kpm=kpm)
@@ -737,7 +753,7 @@ class DecoderEngine(_StackBase):
         pad, S = self.cfg["pad_id"], ids.shape[1]
         Sd, M = S - 1, Bn * (S - 1)
         self.p_drop = self.cfg["dropout"] if training else 0.0
-        if self._ss_ok(Sd, Te):         # one launch per layer fills every CU: nothing to run beside the encoder
+        if self._ss_ok(Sd, Te, Bn):     # one workgroup per sample fills every CU: nothing to run beside the encoder
             self._prefix = None
             return
         b = self.buf((Bn, Te, S))
@@ -754,7 +770,7 @@ class DecoderEngine(_StackBase):
         d, L = self.cfg["d"], self.cfg["layers"]
         M = Bn * Sd
         prefix, self._prefix = self._prefix, None
-        if self._ss_ok(Sd, Te) and prefix is None:
+        if self._ss_ok(Sd, Te, Bn) and prefix is None:
             x = self._embed(b, ids, Sd, M)
             self._kv_prefetched, self._kv_inplace = None, set()
             x, y = self._stack_ss(b, [f"decoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, Bn, Sd,

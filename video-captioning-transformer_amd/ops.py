@@ -651,7 +651,10 @@ def masked_stream(cu_bits, device=None):
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
-TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6}
+TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6,
+        # data-parallel exchange (trainer.ShardedExchange): what the compute stream WAITS for the communicator at the end of a step,
+        # and how long each gradient bucket (reduce-scatter -> Adam on the shard -> all-gather -> cast) occupies the communicator's stream
+        "comm_wait": 7, **{f"comm_b{i}": 8 + i for i in range(8)}}
 _taps_on = False
 _taps_only = None        # None = every tag, else the set of tags that are bracketed
 

@@ -53,6 +53,12 @@ class GradExchange:
             ops.cast(g, s)
             g = s
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if g.is_cuda and not self._avg:
+            # gloo carrying CUDA buffers (several ranks sharing one GPU in the tests): its staging copy runs on a pool stream
+            # behind an event of the current stream; seen once in a while with 4 ranks time-slicing one GPU: a rank's bucket read
+            # before its producers had finished.  The host waits for the stream here (test path only; RCCL is stream-ordered
+            # through the library's own event edges and never takes this branch)
+            torch.cuda.current_stream().synchronize()
         self._work.append((dist.all_reduce(g, op=op, group=self.group, async_op=True), i))
 
     def finish(self, on_bucket_done=None):
@@ -132,6 +138,9 @@ class ShardedExchange:
         if coll.owns_stream:
             ops.stream_wait(coll.stream, cur)          # the communicator's stream follows everything enqueued so far
         with self._on_comm():
+            tag = f"comm_b{i}" if i < 8 else None          # live timing bracket of this bucket on the communicator's stream
+            if tag:
+                ops.tap(tag, 0)
             src = g
             if self._stage is not None:
                 ops.cast(g[a:b], self._stage[a:b])
@@ -141,6 +150,8 @@ class ShardedExchange:
                 if src is not g:
                     ops.cast(src[a:b], g[a:b])
                 self.opt.step_range(a, b)
+                if tag:
+                    ops.tap(tag, 1)
                 return
             lo, hi, n = sh
             coll.reduce_scatter_avg(src[a:b], n, after=False)
@@ -149,9 +160,13 @@ class ShardedExchange:
             self.opt.step_range(lo, hi)
             coll.all_gather(p[a:b], n, after=False)
             m._ps.cast_range(a, b)
+            if tag:
+                ops.tap(tag, 1)
 
     def finish(self):
+        ops.tap("comm_wait", 0)                  # compute stream: from "backward enqueued" to "the communicator's stream has drained"
         self.coll.wait()
+        ops.tap("comm_wait", 1)
         self.opt.finish_ranges()
 
     def gather_optimizer_state(self):
