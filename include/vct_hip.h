@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 7
+#define VCT_ABI_VERSION 8
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -475,6 +475,44 @@ typedef struct vct_decode_block_desc {
 } vct_decode_block_desc;
 int vct_decode_block_supported(int dtype, int d, int H, int ff, int Lk);
 int vct_decode_block(const vct_decode_block_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched greedy-decode step, ONE launch per decoder-layer block (bf16, 2 <= batch <= 256, d = 512, 8 heads): the batch-1 block design
+ * (vct_decode_block) on 16-row MFMA tiles (csrc/vct_decode_bblock.hip).
+ * replaces: CapDecoder.decode_word's module calls for all captions of the batch at one position (reference model/CapDecoder.py:62-79,
+ * called from MMT4Caption.py:163-166; torch nn/modules/transformer.py:1143-1199) -- the 8 launches per layer of the
+ * vct_decode_linear / vct_attn_fwd path.
+ *   kind 0 self-attention block   grid (8 heads, B/16): rows x = prologue; q | k | v of head h -> cache slot; attention over the Lk
+ *                                 cached positions (the last one = this step's); partial out-projection -> part_out[h]
+ *   kind 1 cross-attention block  the same with the q projection only; keys / values = the memory's (computed once per decode)
+ *   kind 2 feed-forward block     grid (ff/256, B/16): act(x W1[256 rows]^T + b1) -> partial x W2[:, 256 cols]^T -> part_out[c]
+ *   kind 3 closing rows           y_out (bf16) = prologue rows (norm3 + decoder.norm over the last block's partials)
+ * prologue: x[row] = table[ids[row*id_stride]] + pos_row (ids != NULL), else res[row] (+ res_bias) + sum_{c < n_part} part[c][row]
+ *   (part[c] = part + c*part_stride, rows of 512 fp32), then LayerNorm(g1, b1) and LayerNorm(g2, b2) where given; the workgroups
+ *   with blockIdx.x == 0 store x to x_out (fp32, the next block's residual).
+ * w_a / w_b: FRAGMENT-MAJOR packed weights (vct_pack_frag): dst[(tile*ksteps + s)*512 + lane*8 + j] =
+ *   W[16*tile + (lane & 15)][32*s + (lane >> 4)*8 + j].  kind 0: w_a = packed in_proj_weight [1536, 512], a_tile = {0, 32, 64};
+ *   kind 1: w_a = packed in_proj_weight (rows 0..511 used), a_tile[0] = 0; w_b = packed out_proj.weight (b_ksteps = 16);
+ *   kind 2: w_a = packed linear1.weight, w_b = packed linear2.weight (b_ksteps = ff/32).  b_a = the first product's bias.
+ * slot (kind 0): q | k | v of the consumed token, row (m) at slot + m*slot_bs; kc / vc: cached keys / values, position j of row m at
+ *   kc + m*kv_bs + j*kv_ld (+ head*64).  Lk <= 64.
+ * vct_decode_bblock_supported: bf16, d = 512, H = 8, ff a multiple of 256 and <= 2048, B <= 256, Lk <= 64.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_decode_bblock_desc {
+  int32_t kind, B, ff, Lk, act, b_ksteps;
+  int32_t a_tile[3]; int32_t n_part;
+  const int64_t* ids; int64_t id_stride; const float* table; const float* pos_row;
+  const float* res; int64_t ld_res; const float* res_bias; const float* part; int64_t part_stride;
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  float* x_out; int64_t ld_xout;
+  const void* w_a; const float* b_a; void* slot; int64_t slot_bs;
+  const void* kc; const void* vc; int64_t kv_ld; int64_t kv_bs;
+  const void* w_b; float* part_out; int64_t part_out_stride;
+  void* y_out; int64_t ld_y;
+} vct_decode_bblock_desc;
+int vct_decode_bblock_supported(int dtype, int d, int H, int ff, int B, int Lk);
+int vct_decode_bblock(const vct_decode_bblock_desc* d, void* stream);
+int vct_pack_frag(const void* w, int64_t ldw, int rows, int cols, void* dst, void* stream);
 
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);

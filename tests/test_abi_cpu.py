@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 8
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -84,6 +84,8 @@ int main(void) {
          sizeof(vct_attn_desc), offsetof(vct_attn_desc, d_o), offsetof(vct_attn_desc, q_bs));
   printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_desc), offsetof(vct_layer_ss_desc, wpk), offsetof(vct_layer_ss_desc, n2),
          offsetof(vct_layer_ss_desc, key_pad), offsetof(vct_layer_ss_desc, site_n3), sizeof(vct_ss_pack_seg), offsetof(vct_ss_pack_seg, dst_chunk));
+  printf("%zu %zu %zu %zu\\n", sizeof(vct_decode_bblock_desc), offsetof(vct_decode_bblock_desc, ids), offsetof(vct_decode_bblock_desc, w_a),
+         offsetof(vct_decode_bblock_desc, ld_y));
   return 0;
 }''')
     exe = tmp_path / "sz"
@@ -92,7 +94,9 @@ int main(void) {
     G, A = _lib.GemmDesc, _lib.AttnDesc
     S, P = _lib.LayerSsDesc, _lib.SsPackSeg
     assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset,
-                   ctypes.sizeof(S), S.wpk.offset, S.n2.offset, S.key_pad.offset, S.site_n3.offset, ctypes.sizeof(P), P.dst_chunk.offset]
+                   ctypes.sizeof(S), S.wpk.offset, S.n2.offset, S.key_pad.offset, S.site_n3.offset, ctypes.sizeof(P), P.dst_chunk.offset,
+                   ctypes.sizeof(_lib.DecodeBBlockDesc), _lib.DecodeBBlockDesc.ids.offset, _lib.DecodeBBlockDesc.w_a.offset,
+                   _lib.DecodeBBlockDesc.ld_y.offset]
 
 
 def test_layer_ss_entry_points_validate_arguments(lib_path):
@@ -114,6 +118,14 @@ def test_layer_ss_entry_points_validate_arguments(lib_path):
     d.nchunks = 95
     assert lib.vct_layer_ss_fwd(d, 1, None) in (-1, -2)                            # (stream length does not match the layer)
     assert lib.vct_ss_pack(None, 1, None, None) == -1
+    # batched block decode (csrc/vct_decode_bblock.hip)
+    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 128, 30) == 1
+    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 4096, 128, 30) == 0 and lib.vct_decode_bblock_supported(_lib.BF16, 768, 8, 2048, 128, 30) == 0
+    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 257, 30) == 0 and lib.vct_decode_bblock_supported(_lib.F32, 512, 8, 2048, 16, 30) == 0
+    assert lib.vct_decode_bblock(None, None) == -1 and lib.vct_pack_frag(None, 512, 512, 512, None, None) == -1
+    bd = _lib.DecodeBBlockDesc()
+    bd.kind, bd.B = 0, 16
+    assert lib.vct_decode_bblock(bd, None) == -1                                    # no input rows
 
 
 def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):

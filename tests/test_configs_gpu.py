@@ -193,16 +193,18 @@ def test_cfgB_greedy_decode_batch128_vs_oracle():
     assert n > 0.9 * ref_ys.size
 
 
-@pytest.mark.parametrize("B,path", [(1, "block"), (1, "gemv"), (16, "skinny"), (128, "skinny")])
+@pytest.mark.parametrize("B,path", [(1, "block"), (1, "gemv"), (16, "bblock"), (16, "skinny"), (128, "bblock"), (128, "skinny"), (37, "bblock")])
 def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
-    """The bf16 token step that bench.py times -- batch 1: weight-streaming matrix-vector kernels (vct_decode_gemv), batch >= 2:
-    skinny MFMA projections with LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
+    """The bf16 token step that bench.py times -- batch 1: weight-streaming matrix-vector kernels (vct_decode_gemv / vct_decode_block),
+    batch >= 2: one launch per layer block on 16-row MFMA tiles (vct_decode_bblock, the default) or skinny MFMA projections with
+    LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
     caption: the predicted next id must be the reference's wherever its top-2 logit margin is resolvable in bf16 (> 0.15),
     over >= 9 positions.  Batch 1 / 16: ids and margins recorded from the reference (cfgB_decode.npz); batch 128: the oracle.
     Batch 1 runs both of its kernels: one launch per layer block (vct_decode_block, the default) and one per stage (vct_decode_gemv)."""
     from vct_amd import decode, engine
     if path == "gemv":
         monkeypatch.setattr(engine.DecoderEngine, "block_decode", False)
+    monkeypatch.setattr(engine.DecoderEngine, "bblock_decode", path == "bblock")      # (off by default: measured slower, engine.py)
     z = load_golden("cfgB_decode.npz")
     mc, V = model_config_of(z), int(z["vocab"])
     cfg = O.cfg_from_model_config(mc, V)
@@ -211,7 +213,7 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
         p = O.init_params(cfg, seed=int(z["param_seed"]))
         f = O.synthetic_batch(B, 12, 512, 20, V, seed=int(z[f"feats_seed_b{B}"]))[0]
         ref_ys, margins = z[f"ys_b{B}"], z[f"margins_b{B}"]
-    else:
+    else:                                                          # 128, and 37: a ragged last row tile (37 = 2 * 16 + 5)
         p = O.init_params(cfg, seed=778)
         f = O.synthetic_batch(B, 12, 512, 20, V, seed=21)[0]
         ref_ys, margins = O.greedy_decode_ids(p, cfg, f, None, max_len=steps + 1, return_margins=True)
@@ -224,6 +226,7 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
         assert engine._decoder_block_decode_ok(dec, st) == (path == "block") and engine._decoder_small_decode_ok(dec, st)
     else:
         assert engine._decoder_fused_decode_ok(dec, st) and not engine._decoder_small_decode_ok(dec, st)
+        assert engine._decoder_bblock_decode_ok(dec, st) == (path == "bblock")
     feats = torch.from_numpy(f).to(DEV)
     ref = torch.from_numpy(np.ascontiguousarray(ref_ys[:, :steps + 1])).to(DEV)
     nxt, lgb = decode.teacher_forced_next_ids(mb, feats, None, ref, steps, return_logits=True)
@@ -231,7 +234,7 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
     ok = margins[:, :steps] > 0.15
     assert ok.sum() >= 0.25 * ok.size and ok[:, :9].any(axis=0).sum() >= (9 if B > 1 else 4)
     assert np.array_equal(nxt[ok], ref_ys[:, 1:steps + 1][ok]), (nxt[ok] != ref_ys[:, 1:steps + 1][ok]).sum()
-    if B <= 16:
+    if B <= 37:
         # every position, not only the clear-margin ones: the step's logits against the oracle's decode_word (bf16 tolerance)
         mem = O.mm_encoder_forward(p, cfg, f, None)[0]
         nb = min(B, 4)
@@ -244,7 +247,7 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
     nxt32, lg32 = decode.teacher_forced_next_ids(m32, feats, None, ref, steps, return_logits=True)
     ok32 = margins[:, :steps] > 5e-5
     assert np.array_equal(nxt32.cpu().numpy()[ok32], ref_ys[:, 1:steps + 1][ok32])
-    if B <= 16:
+    if B <= 37:
         assert rel(lg32[:1, steps - 1], O.decode_word(p, cfg, mem[:1], ref_ys[:1, :steps])) < 1e-4
 
 

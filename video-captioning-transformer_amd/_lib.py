@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -93,6 +93,14 @@ class DecodeBlockDesc(C.Structure):
                 ("sel_ws", vp), ("tok_out", vp), ("end_id", i64), ("ended", vp), ("ended_count", vp), ("all_ended_at", vp), ("t", i32), ("pad1", i32)]
 
 
+class DecodeBBlockDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("ff", i32), ("Lk", i32), ("act", i32), ("b_ksteps", i32), ("a_tile", i32 * 3), ("n_part", i32),
+                ("ids", vp), ("id_stride", i64), ("table", vp), ("pos_row", vp), ("res", vp), ("ld_res", i64), ("res_bias", vp),
+                ("part", vp), ("part_stride", i64), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("x_out", vp), ("ld_xout", i64),
+                ("w_a", vp), ("b_a", vp), ("slot", vp), ("slot_bs", i64), ("kc", vp), ("vc", vp), ("kv_ld", i64), ("kv_bs", i64),
+                ("w_b", vp), ("part_out", vp), ("part_out_stride", i64), ("y_out", vp), ("ld_y", i64)]
+
+
 DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}
 
 _SIGS = {
@@ -128,6 +136,9 @@ _SIGS = {
     "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
     "vct_decode_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_decode_block": (C.c_int, [C.POINTER(DecodeBlockDesc), vp]),
+    "vct_decode_bblock_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vct_decode_bblock": (C.c_int, [C.POINTER(DecodeBBlockDesc), vp]),
+    "vct_pack_frag": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp]),
     "vct_decode_linear": (C.c_int, [C.POINTER(DecodeLinearDesc), vp]),
     "vct_decode_ln2": (C.c_int, [C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),

@@ -88,6 +88,9 @@ class ParamSet:
         # STREAM-ORDER packed copies of whole stacks (key -> [tensor, chunks per layer, [[start, end, blocks, dirty] per layer]]): the operand of the
         # sample-stationary layer kernels (ops.layer_ss_fwd), kept in step with the shadow exactly like the eager transposed copies
         self.packed = {}
+        # MFMA-fragment-major copies of single decoder weights (name -> [tensor, version]): operands of the batched block decode
+        # (ops.decode_bblock), refreshed on demand like the lazy transposed copies (decode entry points)
+        self.fragpacked = {}
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
         self.cast_ranges, start = [], 0
         for n in self.names:
@@ -181,6 +184,17 @@ class ParamSet:
                 sub[3] = False
         return ent[0], ent[1]
 
+    def want_fragpack(self, name: str) -> torch.Tensor:
+        """The 2-D weight `name` in MFMA-fragment-major order (include/vct_hip.h, vct_pack_frag), created on first use and re-packed
+        HERE or by refresh_lazy_transposed() when the shadow has changed since (`version`)."""
+        ent = self.fragpacked.get(name)
+        if ent is None:
+            ent = self.fragpacked[name] = [torch.empty(self.c[name].numel(), dtype=self.compute_dtype, device=self.device), -1]
+        if ent[1] != self.version:
+            ops.pack_frag(self.c[name], ent[0])
+            ent[1] = self.version
+        return ent[0]
+
     def refresh_lazy_transposed(self):
         """Bring every on-demand transposed copy up to date (decode entry points call this before replaying captured steps,
         which bake the copies' addresses but cannot notice that the weights moved on)."""
@@ -188,6 +202,10 @@ class ParamSet:
             if not ent[3] and ent[4] != self.version:
                 ops.transpose(self.c[name], ent[0])
                 ent[4] = self.version
+        for name, ent in self.fragpacked.items():
+            if ent[1] != self.version:
+                ops.pack_frag(self.c[name], ent[0])
+                ent[1] = self.version
 
     def refresh_transposed(self, a: int, b: int, skip=()):
         """Shadow elements [a, b) were just rewritten: eager transposed copies inside follow (except `skip`: already written by
@@ -1188,9 +1206,61 @@ def _decoder_decode_step_fused(self, st: DecodeState, t: int, end_id: int):
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
+def _decoder_bblock_decode_ok(self, st: DecodeState) -> bool:
+    """The batched step with one launch per layer BLOCK (ops.decode_bblock): bf16, d = 512 / 8 heads, ff <= 2048, 2 <= batch <= 256."""
+    d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
+    return (self.bblock_decode and 2 <= st.B <= 256 and self.dev.type == "cuda" and st.Lmax <= 64 and st.Te <= 64
+            and ops.decode_bblock_supported(self.dt, d, H, ff, st.B, min(st.Lmax, 64)))
+
+
+def _decoder_decode_step_bblock(self, st: DecodeState, t: int, end_id: int):
+    """The step of _decoder_decode_step for the whole batch in 3 launches per layer + 3: self-attention block, cross-attention block,
+    feed-forward block on 16-row MFMA tiles (each: first product + attention / activation + the second product split over the
+    workgroups that own the first, as partial row blocks), closing norms, generator, selection.  The partials, the residual, the
+    second product's bias and the LayerNorm(s) are folded by the prologue of the next launch (csrc/vct_decode_bblock.hip)."""
+    d, H, L, Bn, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax, self.cfg["ff"]
+    b = st.b
+    f32 = torch.float32
+    xa, x1, x2 = b.get("bx", (Bn, d), f32), b.get("bx1", (Bn, d), f32), b.get("bx2", (Bn, d), f32)
+    a_part, c_part, f_part = b.get("ba", (H, Bn, d), f32), b.get("bc", (H, Bn, d), f32), b.get("bf", (ff // 256, Bn, d), f32)
+    FP = self.ps.want_fragpack
+    prev = None                                   # (bias of linear2, norm3) of the layer below
+    for l in range(L):
+        lp = f"decoder.layers.{l}."
+        sa, ca = lp + "self_attn.", lp + "multihead_attn."
+        cache = st.kv_self[l]                                              # [B * Lmax, 3d]: q | k | v of every consumed token
+        slot = cache[t - 1]                                                # row (t - 1) of sample 0; sample m at + m * Lmax * 3d
+        kw = dict(w_a=FP(self.pre + sa + "in_proj_weight"), b_a=self.F(sa + "in_proj_bias"), a_tile=(0, d // 16, 2 * d // 16), slot=slot,
+                  slot_bs=Lmax * 3 * d, kv=(cache[:, d:2 * d], cache[:, 2 * d:], 3 * d, Lmax * 3 * d), Lk=t,
+                  w_b=FP(self.pre + sa + "out_proj.weight"), part_out=a_part, x_out=xa)
+        if prev is None:      # x = Emb[ys[:, t-1]] + pos[t-1]
+            ops.decode_bblock("self", Bn, embed=(st.ys[:, t - 1], self.F("tgt_to_emb.weight"), self.pos[t - 1]), **kw)
+        else:                 # x = norm3(x2 + linear2 of the layer below)
+            ops.decode_bblock("self", Bn, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1], **kw)
+        kvc = st.kv_cross[l]                                               # [B * Te, 2d]
+        ops.decode_bblock("cross", Bn, res=xa, res_bias=self.F(sa + "out_proj.bias"), part=a_part,
+                          ln1=(self.F(lp + "norm1.weight"), self.F(lp + "norm1.bias")), x_out=x1,
+                          w_a=FP(self.pre + ca + "in_proj_weight"), b_a=self.F(ca + "in_proj_bias")[:d], a_tile=(0, 0, 0),
+                          kv=(kvc[:, :d], kvc[:, d:], 2 * d, Te * 2 * d), Lk=Te, w_b=FP(self.pre + ca + "out_proj.weight"), part_out=c_part)
+        ops.decode_bblock("ffn", Bn, res=x1, res_bias=self.F(ca + "out_proj.bias"), part=c_part,
+                          ln1=(self.F(lp + "norm2.weight"), self.F(lp + "norm2.bias")), x_out=x2,
+                          w_a=FP(self.pre + lp + "linear1.weight"), b_a=self.F(lp + "linear1.bias"), w_b=FP(self.pre + lp + "linear2.weight"),
+                          b_ksteps=ff // 32, part_out=f_part, ff=ff, act=self.cfg["activation"])
+        prev = (self.F(lp + "linear2.bias"), (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias")))
+    y = b.get("fy", (Bn, d), self.dt)
+    ops.decode_bblock("final", Bn, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1],
+                      ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), y_out=y)
+    logits = b.get("logits", (Bn, self.Vp), self.dt)
+    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=self.gemm_ws())
+    st.last_logits = logits          # [B, Vp] of this step (decode.teacher_forced_next_ids reads it)
+    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
+
+
 def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
     if _decoder_block_decode_ok(self, st):
         return _decoder_decode_step_block(self, st, t, end_id)
+    if _decoder_bblock_decode_ok(self, st):
+        return _decoder_decode_step_bblock(self, st, t, end_id)
     if _decoder_small_decode_ok(self, st):
         return _decoder_decode_step_small(self, st, t, end_id)
     if _decoder_fused_decode_ok(self, st):
@@ -1208,6 +1278,14 @@ DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 
+# A/B switch: 3 launches per layer at batch 2..256 (bf16, vct_decode_bblock).  Built, tested (teacher-forced against the reference /
+# oracle at batch 16 / 37 / 128), measured SLOWER and therefore off: graph-replayed token step at cfg-B 124.7 / 136.5 / 142.5 / 156.2 us
+# at batch 2 / 16 / 128 / 256 against 98.6 / 104.9 / 116.7 / 151.5 us for the launch-per-projection step (tools/decode_bblock_probe.py,
+# gpurun_out/r4: same box).  A block launch has (heads x row tiles) = 64 workgroups at batch 128, each pulling its head's weights
+# (256 KB), the 8 partial row blocks + residual of the previous block (320 KB fp32) and its rows' cached keys / values through ONE
+# CU's L2 path (~50 B/clk): >= 6 us of operand traffic per launch before any latency, on a quarter of the chip -- the skinny kernels
+# spread the same bytes over 256 workgroups.  (At batch 1 the same design wins because a partial is a 2 KB vector.)
+DecoderEngine.bblock_decode = os.environ.get("VCT_BBLOCK_DECODE", "0") == "1"
 DecoderEngine.block_decode = os.environ.get("VCT_BLOCK_DECODE", "1") != "0"   # A/B switch: 3 launches per layer at batch 1 (bf16)
 DecoderEngine.small_batch_decode = True       # A/B switch: weight-streaming GEMV step for batch <= 4
 DecoderEngine.decode_begin = _decoder_decode_begin

@@ -541,6 +541,60 @@ def decode_block_supported(dtype, d: int, H: int, ff: int, Lk: int) -> bool:
     return r
 
 
+_bb_ok = {}
+
+
+def decode_bblock_supported(dtype, d: int, H: int, ff: int, B: int, Lk: int) -> bool:
+    if dtype != torch.bfloat16:
+        return False
+    key = (d, H, ff, B, Lk)
+    r = _bb_ok.get(key)
+    if r is None:
+        r = _bb_ok[key] = bool(L.load().vct_decode_bblock_supported(L.BF16, d, H, ff, B, Lk))
+    return r
+
+
+def pack_frag(w: torch.Tensor, dst: torch.Tensor):
+    """dst <- the bf16 matrix w [N, K] in MFMA-fragment-major order (include/vct_hip.h, vct_pack_frag)."""
+    assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and dst.numel() >= w.numel()
+    L.check(L.load().vct_pack_frag(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], dst.data_ptr(), L.stream_ptr()), "vct_pack_frag")
+    return dst
+
+
+def decode_bblock(kind: str, B: int, *, embed=None, res=None, res_bias=None, part=None, ln1=None, ln2=None, x_out=None, w_a=None, b_a=None,
+                  a_tile=(0, 0, 0), slot=None, slot_bs=0, kv=None, Lk=0, w_b=None, b_ksteps=16, part_out=None, ff=0, act=None, y_out=None):
+    """One block of the batched decode step (include/vct_hip.h, vct_decode_bblock).  kind: 'self' | 'cross' | 'ffn' | 'final'.
+    embed = (ids 1-D view, table, pos_row); part = [n_part, B, 512] fp32 partials of the previous block; kv = (k view, v view, row
+    stride, sample stride); part_out = [n, B, 512] fp32."""
+    q = L.DecodeBBlockDesc()
+    q.kind, q.B, q.ff, q.Lk, q.act, q.b_ksteps = {"self": 0, "cross": 1, "ffn": 2, "final": 3}[kind], int(B), int(ff), int(Lk), L.ACT[act], int(b_ksteps)
+    q.a_tile[0], q.a_tile[1], q.a_tile[2] = (int(t) for t in a_tile)
+    if embed is not None:
+        ids, table, pos_row = embed
+        q.ids, q.id_stride, q.table, q.pos_row = ids.data_ptr(), ids.stride(0), table.data_ptr(), pos_row.data_ptr()
+    if res is not None:
+        q.res, q.ld_res = res.data_ptr(), res.stride(0)
+    q.res_bias = L.ptr(res_bias)
+    if part is not None:
+        q.part, q.part_stride, q.n_part = part.data_ptr(), part.stride(0), part.shape[0]
+    if ln1 is not None:
+        q.g1, q.b1 = ln1[0].data_ptr(), ln1[1].data_ptr()
+    if ln2 is not None:
+        q.g2, q.b2 = ln2[0].data_ptr(), ln2[1].data_ptr()
+    if x_out is not None:
+        q.x_out, q.ld_xout = x_out.data_ptr(), x_out.stride(0)
+    q.w_a, q.b_a, q.w_b = L.ptr(w_a), L.ptr(b_a), L.ptr(w_b)
+    if slot is not None:
+        q.slot, q.slot_bs = slot.data_ptr(), int(slot_bs)
+    if kv is not None:
+        q.kc, q.vc, q.kv_ld, q.kv_bs = kv[0].data_ptr(), kv[1].data_ptr(), int(kv[2]), int(kv[3])
+    if part_out is not None:
+        q.part_out, q.part_out_stride = part_out.data_ptr(), part_out.stride(0)
+    if y_out is not None:
+        q.y_out, q.ld_y = y_out.data_ptr(), y_out.stride(0)
+    L.check(L.load().vct_decode_bblock(q, L.stream_ptr()), "vct_decode_bblock")
+
+
 def transpose(src: torch.Tensor, dst: torch.Tensor):
     """dst[c, r] = src[r, c] (bf16; row strides free)."""
     L.check(L.load().vct_transpose(L.dtype_code(src.dtype), src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
