@@ -207,7 +207,7 @@ int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
  * vct_add_ln_ln_fwd launches of one layer on the unfused path.  It SAVES exactly what those save (qkv, o, a, y, mean, rstd,
  * cross q / kv / o / a, pre-activation, dropped activation, f) and draws the same dropout counter streams
  * (site_*: attention probabilities, residual dropouts, feed-forward dropout), so the unfused backward kernels run behind it.
- *   x bf16 [B*L, 512] layer input; mem bf16 [B*Lm, 512] (decoder layers; NULL = encoder layer: no cross-attention block,
+ *   x bf16 [B*L, 512] layer input (an OUTPUT when layers[0].pro != 0: the rows the prologue builds); mem bf16 [B*Lm, 512] (decoder layers; NULL = encoder layer: no cross-attention block,
  *   n2 unused).  Self-attention masks as vct_attn_desc (causal; key_pad + key_pad_shift; key_ids / pad_id).
  *   wpk: the layer's weights packed in STREAM ORDER by vct_ss_pack -- 64-KiB chunks (one 512-row block x 64 K columns of a
  *   weight, as 8 waves x 8 MFMA fragments of 1 KiB: wave w, column tile t < 4, k-step s < 2 = rows 64w + 16t .. +15,
@@ -241,7 +241,15 @@ typedef struct vct_layer_ss_desc {
   const uint8_t* key_pad; const int64_t* key_ids; int64_t key_ids_bs; int64_t pad_id;
   const uint32_t* seed; float p_drop;
   uint32_t site_sa, site_n1, site_ca, site_n2, site_ff, site_n3;
-  uint32_t pad0;
+  uint32_t site_emb;
+  /* stack prologue (layers[0] only): pro = 0: x is the input.  pro = 1 (encoder stacks): x is BUILT from the frame features --
+   * u = feats W_u^T + b_unify (the unify weight's 512 x 512 block = the FIRST 8 chunks of the stream, in front of layer 0's),
+   * row 0 = mean_t(u) + pe_rows[0], row t+1 = u_t + pe_rows[t+1] (MMEncoder.py:246-271) -- stored to x, and the bf16 copy of fp32
+   * features to x_in (what the unify weight gradient reads; NULL when feats are bf16).  pro = 2 (decoder stacks): x = dropout(
+   * emb_table[emb_ids[b, s]] + emb_pos[s]) (CapDecoder.py:48, Embedding.py:23-25; counter stream of vct_embed_fwd, site_emb) -- stored to x. */
+  int32_t pro, feats_dtype;
+  const void* feats; void* x_in; const float* b_unify; const float* pe_rows;
+  const int64_t* emb_ids; int64_t emb_ids_bs; const float* emb_table; const float* emb_pos;
 } vct_layer_ss_desc;
 typedef struct vct_ss_pack_seg { const void* w; int64_t ldw; int32_t nchunks; int32_t reserved; int64_t dst_chunk; } vct_ss_pack_seg;
 int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm);

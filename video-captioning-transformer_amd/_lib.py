@@ -62,7 +62,9 @@ class LayerSsDesc(C.Structure):
                 ("n1", SsNorm), ("b_cq", vp), ("b_ckv", vp), ("b_co", vp), ("cq", vp), ("ckv", vp), ("co", vp), ("ca", vp),
                 ("n2", SsNorm), ("b1", vp), ("b2", vp), ("hpre", vp), ("h", vp), ("f", vp), ("n3", SsNorm), ("nf", SsNorm),
                 ("key_pad", vp), ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64), ("seed", vp), ("p_drop", f32),
-                ("site_sa", u32), ("site_n1", u32), ("site_ca", u32), ("site_n2", u32), ("site_ff", u32), ("site_n3", u32), ("pad0", u32)]
+                ("site_sa", u32), ("site_n1", u32), ("site_ca", u32), ("site_n2", u32), ("site_ff", u32), ("site_n3", u32), ("site_emb", u32),
+                ("pro", i32), ("feats_dtype", i32), ("feats", vp), ("x_in", vp), ("b_unify", vp), ("pe_rows", vp),
+                ("emb_ids", vp), ("emb_ids_bs", i64), ("emb_table", vp), ("emb_pos", vp)]
 
 
 class SsPackSeg(C.Structure):

@@ -80,8 +80,13 @@ struct SsLayerP {
   int B, L, Lm;                      // samples, rows per sample (<= 32), memory rows per sample (<= 16; decoder layers)
   int ff, act, last, causal, nl;
   const bf16_t* wpk; int nchunks;    // packed weight stream of ALL nl layers, back to back (stream order, see vct_ss_pack)
-  const bf16_t* x;                   // [B*L, 512] input of the first layer
+  bf16_t* x;                         // [B*L, 512] input of the first layer (pro == 0), or where the prologue stores the rows it builds
   const bf16_t* mem;                 // [B*Lm, 512] encoder memory (decoder layers)
+  // stack prologue: 0 = x is given; 1 = encoder front end (MMEncoder.py:244-273: unify Linear, mean token, temporal encoding; the unify
+  // weight is the first 8 chunks of the stream); 2 = token embedding + positional rows + dropout (CapDecoder.py:48, Embedding.py:23-25)
+  int pro;
+  const void* feats; int feats_f32; bf16_t* x_in; const float* b_u; const float* pe;      // pro 1: feats [B*(L-1), 512], bf16 copy out, bias, PE' rows [L, 512]
+  const int64_t* emb_ids; long emb_ids_bs; const float* emb_table; const float* emb_pos; uint32_t site_emb;   // pro 2
   SsNorm nf;                         // stack-final norm behind the last layer (last != 0)
   // masks of the self-attention (as vct_attn_desc)
   const uint8_t* key_pad; int key_pad_shift;
@@ -463,9 +468,96 @@ __global__ __launch_bounds__(SS_NT, SS_NW / 4) void layer_ss_fwd_kernel(const Ss
   ws_fetch(ws, b0);                                        // the stream starts before the first activation byte is here,
   ws_fetch(ws, b1);                                        // two chunks ahead: both buffers are in flight between products
 
-  global_to_panel(R0, SS_PSTR, L, MT * 16, p.x, SS_D, grow0, tid0);
   if constexpr (CROSS) global_to_panel(RMp, SS_PSTR, p.Lm, 16, p.mem, SS_D, (long)b * p.Lm, tid0);
   const unsigned long long padmask = ss_padmask(p, b, lane0);
+  if (!CROSS && p.pro == 1) {
+    // ---- encoder front end: u = feats W_u^T + b_u;  rows 1..T = u + PE',  row 0 = mean_t(u) + PE'[0]  (all T frames, pads included) ----
+    const int T = L - 1, li = lane0 & 15, lg = lane0 >> 4;
+    for (int v = tid0; v < MT * 16 * (SS_D / 8); v += SS_NT) {          // frames -> bf16 panel R1A (rows >= T zero) [+ the bf16 copy the unify dW reads]
+      const int r = v / (SS_D / 8), c = (v % (SS_D / 8)) * 8;
+      BV8s val;
+      if (r < T) {
+        const long g = ((long)b * T + r) * SS_D + c;
+        if (p.feats_f32) {
+          const float4 f0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.feats) + g);
+          const float4 f1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.feats) + g + 4);
+          val.e[0] = f2bf(f0.x); val.e[1] = f2bf(f0.y); val.e[2] = f2bf(f0.z); val.e[3] = f2bf(f0.w);
+          val.e[4] = f2bf(f1.x); val.e[5] = f2bf(f1.y); val.e[6] = f2bf(f1.z); val.e[7] = f2bf(f1.w);
+          if (p.x_in != nullptr) *reinterpret_cast<BV8s*>(p.x_in + g) = val;
+        } else {
+          val = *reinterpret_cast<const BV8s*>(reinterpret_cast<const bf16_t*>(p.feats) + g);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) val.e[j] = 0;
+      }
+      *reinterpret_cast<BV8s*>(R1A + r * SS_PSTR + c) = val;
+    }
+    float4 bu[SS_TPW];
+    load_bias4(bu, p.b_u, wave * SS_CPW, lg);
+    ss_barrier();
+    f32x4 au[MT][SS_TPW];
+    acc_zero<MT>(au);
+    wave_gemm<MT>(au, R1A + li * SS_PSTR + lg * 8, SS_PSTR, 0, 8, ws, b0, b1);
+    const float invT = 1.0f / (float)T;
+#pragma unroll
+    for (int t = 0; t < SS_TPW; t++) {
+      const int col = wave * SS_CPW + t * 16 + lg * 4;
+      float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      const float bb[4] = {bu[t].x, bu[t].y, bu[t].z, bu[t].w};
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const int fr = m * 16 + li;                                     // frame index; its row in the stack input is fr + 1
+        const bool valid = fr < T;
+        const float4 pe4 = *reinterpret_cast<const float4*>(p.pe + (long)min(fr + 1, T) * SS_D + col);
+        const float pp[4] = {pe4.x, pe4.y, pe4.z, pe4.w};
+        BV4 z;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float u = bf2f(f2bf(au[m][t][r] + bb[r]));              // u as the unfused path stores it (bf16), then + PE'
+          cs[r] += valid ? u : 0.0f;
+          z.e[r] = valid ? f2bf(u + pp[r]) : (bf16_t)0;
+        }
+        if (fr + 1 < MT * 16) *reinterpret_cast<BV4*>(R0 + (fr + 1) * SS_PSTR + col) = z;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) cs[r] = red16_sum(cs[r]);             // over the frames (the 16 lanes that share lg)
+      if (li == 0) {
+        const float4 pe0 = *reinterpret_cast<const float4*>(p.pe + col);
+        BV4 z;
+        z.e[0] = f2bf(cs[0] * invT + pe0.x); z.e[1] = f2bf(cs[1] * invT + pe0.y); z.e[2] = f2bf(cs[2] * invT + pe0.z); z.e[3] = f2bf(cs[3] * invT + pe0.w);
+        *reinterpret_cast<BV4*>(R0 + col) = z;
+      }
+    }
+    ss_barrier();
+    panel_to_global<SS_D>(R0, SS_PSTR, L, p.x, SS_D, grow0, 0, tid0);
+  } else if (CROSS && p.pro == 2) {
+    // ---- token embedding: x = dropout(Emb[ids] + pos) (embed_fwd_kernel's arithmetic and counter stream) --------------------------------
+    const Dropout dre = make_dropout(p.seed, p.site_emb, p.p_drop);
+    for (int v = tid0; v < MT * 16 * (SS_D / 8); v += SS_NT) {
+      const int r = v / (SS_D / 8), c = (v % (SS_D / 8)) * 8;
+      BV8s val;
+      if (r < L) {
+        const long id = p.emb_ids[(long)b * p.emb_ids_bs + r];
+        const float* tr = p.emb_table + id * SS_D + c;
+        const float* pr = p.emb_pos + (long)r * SS_D + c;
+        const float4 t0 = *reinterpret_cast<const float4*>(tr), t1 = *reinterpret_cast<const float4*>(tr + 4);
+        const float4 q0 = *reinterpret_cast<const float4*>(pr), q1 = *reinterpret_cast<const float4*>(pr + 4);
+        float dm[8];
+        drop_mults<8>(dre, (uint32_t)(grow0 + r) * (uint32_t)SS_D + (uint32_t)c, dm);
+        val.e[0] = f2bf((t0.x + q0.x) * dm[0]); val.e[1] = f2bf((t0.y + q0.y) * dm[1]); val.e[2] = f2bf((t0.z + q0.z) * dm[2]);
+        val.e[3] = f2bf((t0.w + q0.w) * dm[3]); val.e[4] = f2bf((t1.x + q1.x) * dm[4]); val.e[5] = f2bf((t1.y + q1.y) * dm[5]);
+        val.e[6] = f2bf((t1.z + q1.z) * dm[6]); val.e[7] = f2bf((t1.w + q1.w) * dm[7]);
+        *reinterpret_cast<BV8s*>(p.x + (grow0 + r) * SS_D + c) = val;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) val.e[j] = 0;
+      }
+      *reinterpret_cast<BV8s*>(R0 + r * SS_PSTR + c) = val;
+    }
+  } else {
+    global_to_panel(R0, SS_PSTR, L, MT * 16, p.x, SS_D, grow0, tid0);
+  }
   constexpr int SS_WPH = SS_NW / SS_H;                     // waves per attention head: they take the query tiles in turn
   const int head = wave / SS_WPH, qt0 = wave % SS_WPH, hd0 = head * SS_HD;
   // panels of the feed-forward phase (slot plan: DESIGN.md): input rows, the two activation buffers, f, y (= the next layer's x), y2
@@ -739,6 +831,13 @@ extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, v
   if (!vct_layer_ss_supported(q->dtype, q->d, q->H, q->ff, q->L, cross ? q->Lm : 0) || q->B < 1) return VCT_E_SHAPE;
   if (cross && q->Lm < 1) return VCT_E_SHAPE;
   const int64_t per_layer = vct_layer_ss_stream_chunks(q->ff, cross);
+  const int pro = q->pro;
+  if (pro < 0 || pro > 2 || (pro == 1 && cross) || (pro == 2 && !cross)) return VCT_E_ARG;
+  if (pro == 1 && (!q->feats || !q->b_unify || !q->pe_rows || q->L < 2 || (q->feats_dtype != VCT_F32 && q->feats_dtype != VCT_BF16) ||
+                   (((uintptr_t)q->feats | (uintptr_t)q->x_in | (uintptr_t)q->b_unify | (uintptr_t)q->pe_rows) & 15)))
+    return VCT_E_ARG;
+  if (pro == 2 && (!q->emb_ids || !q->emb_table || !q->emb_pos || (((uintptr_t)q->emb_table | (uintptr_t)q->emb_pos) & 15))) return VCT_E_ARG;
+  const int64_t pro_chunks = pro == 1 ? 8 : 0;            // the unify weight block in front of layer 0's stream
   if (!q->x || q->key_pad_shift < 0 || (q->key_pad != nullptr && q->key_pad_shift >= q->L)) return q->x ? VCT_E_SHAPE : VCT_E_ARG;
   auto norm_ok = [](const vct_ss_norm& n) { return n.gamma && n.beta && n.y && n.mean && n.rstd; };
   auto cvt = [](const vct_ss_norm& n) { return SsNorm{n.gamma, n.beta, reinterpret_cast<bf16_t*>(n.y), n.mean, n.rstd}; };
@@ -750,7 +849,8 @@ extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, v
         d.key_ids_bs != q->key_ids_bs || d.pad_id != q->pad_id || d.seed != q->seed || d.p_drop != q->p_drop)
       return VCT_E_ARG;
     if (d.nchunks != per_layer) return VCT_E_SHAPE;
-    if (!d.wpk || (const char*)d.wpk != (const char*)q->wpk + (size_t)l * per_layer * SS_CHUNK * 2) return VCT_E_ARG;
+    if (!d.wpk || (const char*)d.wpk != (const char*)q->wpk + (size_t)(l * per_layer + (l > 0 ? pro_chunks : 0)) * SS_CHUNK * 2) return VCT_E_ARG;
+    if (l > 0 && d.pro != 0) return VCT_E_ARG;
     if (d.last && l != n_layers - 1) return VCT_E_ARG;
     if (!d.b_qkv || !d.b_o || !d.qkv || !d.o || !d.a || !d.b1 || !d.b2 || !d.hpre || !d.h || !d.f) return VCT_E_ARG;
     if (!norm_ok(d.n1) || !norm_ok(d.n3) || (d.last && !norm_ok(d.nf))) return VCT_E_ARG;
@@ -779,8 +879,11 @@ extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, v
     memset(&p, 0, sizeof(p));
     p.B = q->B; p.L = q->L; p.Lm = cross ? q->Lm : 0; p.ff = q->ff; p.act = q->act; p.causal = q->causal; p.nl = nl;
     p.last = layers[base + nl - 1].last;
-    p.wpk = reinterpret_cast<const bf16_t*>(layers[base].wpk); p.nchunks = (int)(per_layer * nl);
-    p.x = reinterpret_cast<const bf16_t*>(base == 0 ? q->x : layers[base - 1].n3.y);
+    p.wpk = reinterpret_cast<const bf16_t*>(layers[base].wpk); p.nchunks = (int)(per_layer * nl + (base == 0 ? pro_chunks : 0));
+    p.x = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(base == 0 ? q->x : layers[base - 1].n3.y));
+    p.pro = base == 0 ? pro : 0;
+    p.feats = q->feats; p.feats_f32 = q->feats_dtype == VCT_F32; p.x_in = reinterpret_cast<bf16_t*>(q->x_in); p.b_u = q->b_unify; p.pe = q->pe_rows;
+    p.emb_ids = q->emb_ids; p.emb_ids_bs = q->emb_ids_bs; p.emb_table = q->emb_table; p.emb_pos = q->emb_pos; p.site_emb = q->site_emb;
     p.mem = reinterpret_cast<const bf16_t*>(q->mem);
     p.nf = cvt(layers[base + nl - 1].nf);
     p.key_pad = q->key_pad; p.key_pad_shift = q->key_pad_shift; p.key_ids = q->key_ids; p.key_ids_bs = q->key_ids_bs; p.pad_id = q->pad_id;

@@ -158,26 +158,27 @@ class ParamSet:
         return ent[0]
 
     def want_packed(self, key: str, layers):
-        """(stream, chunks per layer): the weights of a whole Transformer STACK packed, layer after layer, in the order the
-        sample-stationary kernel consumes them (include/vct_hip.h, vct_ss_pack).  layers = [(names, blocks_fn)] per layer, blocks_fn()
-        -> [(2-D shadow view, nchunks, first chunk inside the layer)].  Created on first use; every layer's part is rewritten
-        whenever the shadow of that layer is (refresh_transposed: behind the optimizer's pass, inside the recorded step)."""
+        """(stream, [first chunk of every part]): the weights of a whole Transformer STACK packed, part after part, in the order the
+        sample-stationary kernel consumes them (include/vct_hip.h, vct_ss_pack).  layers = [(names, blocks_fn)] per part (a layer, or
+        the unify weight in front of an encoder stack), blocks_fn() -> [(2-D shadow view, nchunks, first chunk inside the part)].
+        Created on first use; every part is rewritten whenever the shadow of its weights is (refresh_transposed: behind the
+        optimizer's pass, inside the recorded step)."""
         ent = self.packed.get(key)
         if ent is None:
-            per, parts = None, []
+            parts, at, firsts = [], 0, []
             for names, blocks_fn in layers:
                 blocks = blocks_fn()
                 n = max(dc + nch for _w, nch, dc in blocks)
-                assert per is None or per == n
-                per = n
-                parts.append((names, blocks))
-            t = torch.empty(per * len(parts) * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
+                parts.append((names, [(w, nch, dc + at) for w, nch, dc in blocks]))
+                firsts.append(at)
+                at += n
+            t = torch.empty(at * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
             subs = []
-            for l, (names, blocks) in enumerate(parts):
+            for names, blocks in parts:
                 a = min(self.offsets[n] for n in names)
                 b = max(self.offsets[n] + self.params[n].numel() for n in names)
-                subs.append([a, b, [(w, nch, dc + l * per) for w, nch, dc in blocks], True])
-            ent = self.packed[key] = [t, per, subs]
+                subs.append([a, b, blocks, True])
+            ent = self.packed[key] = [t, firsts, subs]
         for sub in ent[2]:
             if sub[3]:
                 ops.ss_pack(sub[2], ent[0])
@@ -555,8 +556,9 @@ class _StackBase:
             return False
         return ops.layer_ss_supported(self.dt, c["d"], c["nhead"], c["ff"], Lr, Lm)
 
-    def _ss_stream(self, lps, cross: bool):
-        """The packed weight stream of the stack's layers `lps` (blocks in the kernel's consumption order, layer after layer)."""
+    def _ss_stream(self, lps, cross: bool, lead=None):
+        """The packed weight stream of the stack's layers `lps` (blocks in the kernel's consumption order, layer after layer); lead =
+        name of a 512 x 512 weight the kernel's prologue consumes first (the encoder's unify Linear)."""
         ff = self.cfg["ff"]
 
         def one(lp):
@@ -583,16 +585,23 @@ class _StackBase:
                     out.append((w2[:, 512 * j:512 * (j + 1)], 8, at)); at += 8
                 return out
             return names, blocks
-        return self.ps.want_packed(self.pre + lps[0] + f"x{len(lps)}", [one(lp) for lp in lps])
+        parts = [one(lp) for lp in lps]
+        if lead is not None:
+            parts.insert(0, ([self.pre + lead], lambda: [(self.ps.c[self.pre + lead][0:512], 8, 0)]))
+        return self.ps.want_packed(self.pre + lps[0] + f"x{len(lps)}" + (lead or ""), parts)
 
-    def _stack_ss(self, b, lps, tags, x, Bn, Lr, sites0, *, ln_tag, ln_name, final, mem=None, Lm=0, causal=False, kpm=None):
+    def _stack_ss(self, b, lps, tags, x, Bn, Lr, sites0, *, ln_tag, ln_name, final, mem=None, Lm=0, causal=False, kpm=None,
+                  frontend=None, embed=None):
         """The layers `lps` (buffer tags `tags`, dropout site bases `sites0`) on input x [Bn*Lr, d] in ONE launch per four layers.
         ln_tag / ln_name: buffer tag and parameter name of a layer's closing norm ('n2.' / 'norm2.' encoder, 'n3.' / 'norm3.' decoder);
         final = parameter prefix of the stack-final norm.  Returns (last layer's output, final-norm output)."""
         d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
         M, cross = Bn * Lr, mem is not None
         f32 = torch.float32
-        wpk, per = self._ss_stream(lps, cross)
+        wpk, firsts = self._ss_stream(lps, cross, lead="unify.0.weight" if frontend is not None else None)
+        if frontend is not None:
+            firsts = firsts[1:]                  # (the kernel's prologue reads the unify block from the head of the stream itself)
+        per = ops.layer_ss_stream_chunks(ff, cross)
         descs, y, y2 = [], x, None
         for l, (lp, tag, site) in enumerate(zip(lps, tags, sites0)):
             b.t[tag + "x"] = y
@@ -616,11 +625,12 @@ class _StackBase:
             nl = norm(tag + ln_tag, lp + ln_name)
             nf = norm("nf.", final) if l == len(lps) - 1 else None
             descs.append(ops.layer_ss_desc(
-                B=Bn, Lr=Lr, x=y, wpk=wpk[l * per * ops.SS_CHUNK:], nchunks=per, ff=ff, act=self.cfg["activation"], H=H, bias=bias,
+                B=Bn, Lr=Lr, x=y, wpk=wpk[(firsts[l] if l else 0) * ops.SS_CHUNK:], nchunks=per, ff=ff, act=self.cfg["activation"], H=H, bias=bias,
                 sa=(b.get(st + "qkv", (M, 3 * d), self.dt), b.get(st + "o", (M, d), self.dt), b.get(st + "a", (M, d), self.dt)),
                 n1=norm(tag + "n1.", lp + "norm1."),
                 ffn=(b.get(tag + "ff.hpre", (M, ff), self.dt), b.get(tag + "ff.h", (M, ff), self.dt), b.get(tag + "ff.f", (M, d), self.dt)),
-                n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites, **kw))
+                n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites,
+                frontend=frontend if l == 0 else None, embed=embed if l == 0 else None, **kw))
             y, y2 = nl[2], (nf[2] if nf is not None else None)
         ops.layer_ss_fwd(descs)
         return y, y2
@@ -678,12 +688,6 @@ class EncoderEngine(_StackBase):
         self.cur, self.shape = b, (B, T)
         Te, M = T + 1, B * (T + 1)
         x_in = feats.reshape(B * T, Ein).contiguous()
-        if x_in.dtype != self.dt:        # fp32 features (reference contract); a DeviceLoader batch may already be bf16
-            x_in = ops.cast(x_in, b.get("feats_c", (B * T, Ein), self.dt))
-        b.t["x_in"] = x_in
-        u = b.get("u", (B * T, d), self.dt)
-        ops.gemm(x_in, self.W("unify.0.weight"), u, bias=self.F("unify.0.bias"))
-        x = ops.enc_frontend_fwd(u, self.pe_rows(T), b.get("x0", (M, d), self.dt), B, T)
         # key-padding of the encoder's self-attention: the raw frame mask with a shift of one (key 0 = the aggregation
         # token, never padded) -- read by the attention kernel directly, no [B, T+1] mask is built
         kpm = None
@@ -691,7 +695,27 @@ class EncoderEngine(_StackBase):
             mk = mask if mask.is_contiguous() else mask.contiguous()
             kpm = (mk.view(torch.uint8) if mk.dtype == torch.bool else mk, 1)
         b.t["kpm_used"] = kpm
-        if self._ss_ok(Te, 0, B):       # the whole stack (+ the stack-final norm) in one launch per four layers
+        if self._ss_ok(Te, 0, B) and Ein == d and x_in.dtype in (torch.float32, self.dt):
+            # the whole stack in one launch per four layers: front end (unify Linear, mean token, temporal encoding) in the kernel's
+            # prologue, the stack-final norm in its last epilogue
+            xc = None
+            if x_in.dtype != self.dt:
+                xc = b.get("feats_c", (B * T, Ein), self.dt)            # bf16 copy of the features: the unify weight gradient's operand
+            b.t["x_in"] = xc if xc is not None else x_in
+            x0 = b.get("x0", (M, d), self.dt)
+            x, mem = self._stack_ss(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x0, B, Te,
+                                    [ENC_SITE + 16 * l for l in range(L)], ln_tag="n2.", ln_name="norm2.",
+                                    final="transformer_encoder.norm.", kpm=kpm,
+                                    frontend=(x_in, xc, self.F("unify.0.bias"), self.pe_rows(T)))
+            b.t["x_last"] = x
+            return mem
+        if x_in.dtype != self.dt:        # fp32 features (reference contract); a DeviceLoader batch may already be bf16
+            x_in = ops.cast(x_in, b.get("feats_c", (B * T, Ein), self.dt))
+        b.t["x_in"] = x_in
+        u = b.get("u", (B * T, d), self.dt)
+        ops.gemm(x_in, self.W("unify.0.weight"), u, bias=self.F("unify.0.bias"))
+        x = ops.enc_frontend_fwd(u, self.pe_rows(T), b.get("x0", (M, d), self.dt), B, T)
+        if self._ss_ok(Te, 0, B):       # (features of another width: the front end stays on its own kernels)
             x, mem = self._stack_ss(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, B, Te,
                                     [ENC_SITE + 16 * l for l in range(L)], ln_tag="n2.", ln_name="norm2.",
                                     final="transformer_encoder.norm.", kpm=kpm)
@@ -789,11 +813,12 @@ class DecoderEngine(_StackBase):
         M = Bn * Sd
         prefix, self._prefix = self._prefix, None
         if self._ss_ok(Sd, Te, Bn) and prefix is None:
-            x = self._embed(b, ids, Sd, M)
             self._kv_prefetched, self._kv_inplace = None, set()
-            x, y = self._stack_ss(b, [f"decoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x, Bn, Sd,
+            x0 = b.get("x0", (M, d), self.dt)                              # built by the kernel's prologue (token embedding + positions + dropout)
+            x, y = self._stack_ss(b, [f"decoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)], x0, Bn, Sd,
                                   [DEC_SITE + 16 * l for l in range(L)], ln_tag="n3.", ln_name="norm3.", final="decoder.norm.",
-                                  mem=mem, Lm=Te, causal=True, kpm=kpm)
+                                  mem=mem, Lm=Te, causal=True, kpm=kpm,
+                                  embed=(ids, self.F("tgt_to_emb.weight"), self.pos, EMB_SITE))
             b.t["x_last"] = x
             return y
         if prefix is not None and prefix[0] is b:        # embedding + bottom self-attention already ran beside the encoder

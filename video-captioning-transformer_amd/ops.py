@@ -223,7 +223,7 @@ def ss_pack(blocks, dst: torch.Tensor):
 
 
 def layer_ss_desc(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, cross=None, n2=None, nf=None, mem=None, Lm=0,
-                  causal=False, key_pad=None, seed=None, p_drop=0.0, sites=(0, 0, 0, 0, 0, 0)):
+                  causal=False, key_pad=None, seed=None, p_drop=0.0, sites=(0, 0, 0, 0, 0, 0), frontend=None, embed=None):
     """Descriptor of ONE layer of a sample-stationary stack launch (include/vct_hip.h, vct_layer_ss_desc).  bias = dict(qkv, o,
     [cq, ckv, co], l1, l2) fp32 vectors; sa = (qkv, o, a); cross = (q, kv, o, a); ffn = (hpre, h, f); nX = (gamma, beta, y, mean, rstd);
     sites = dropout sites (self-attention probabilities, norm1, cross-attention probabilities, norm2, feed-forward, norm3)."""
@@ -259,6 +259,14 @@ def layer_ss_desc(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, 
     if seed is not None and p_drop > 0.0:
         q.seed, q.p_drop = seed.data_ptr(), float(p_drop)
     q.site_sa, q.site_n1, q.site_ca, q.site_n2, q.site_ff, q.site_n3 = (int(s) for s in sites)
+    if frontend is not None:       # (feats [B*T, 512] fp32 / bf16, x_in bf16 copy or None, unify bias, PE' rows [T+1, 512]): x is built and stored
+        feats, x_in, b_u, pe_rows = frontend
+        q.pro, q.feats_dtype, q.feats, q.x_in = 1, L.dtype_code(feats.dtype), feats.data_ptr(), L.ptr(x_in)
+        q.b_unify, q.pe_rows = b_u.data_ptr(), pe_rows.data_ptr()
+    if embed is not None:          # (ids [B, >= L] int64, fp32 table, fp32 positional rows, dropout site): x is built and stored
+        ids, table, pos, site = embed
+        assert ids.dtype == torch.int64 and ids.stride(1) == 1 and ids.shape[1] >= Lr
+        q.pro, q.emb_ids, q.emb_ids_bs, q.emb_table, q.emb_pos, q.site_emb = 2, ids.data_ptr(), ids.stride(0), table.data_ptr(), pos.data_ptr(), int(site)
     return q
 
 
