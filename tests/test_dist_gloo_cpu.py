@@ -210,6 +210,11 @@ def _resume_worker(rank, world, port, q, path):
     n = (b - a) // world
     other = (rank + 1) % world
     stale_before = opt.exp_avg[a + other * n: a + (other + 1) * n].clone()
+    try:                                  # a lone rank asking for the state must get an error, not a hidden (hanging) collective
+        opt.state_dict()
+        guarded = False
+    except RuntimeError:
+        guarded = True
     checkpoint.save_training_state(path, m, opt, epoch=3, write=(rank == 0))     # every rank calls: the gather is a collective
     gathered_now = opt.exp_avg[a + other * n: a + (other + 1) * n].clone()
     dist.barrier()
@@ -223,7 +228,7 @@ def _resume_worker(rank, world, port, q, path):
     own = slice(a + rank * n, a + (rank + 1) * n)
     got = m2.state_dict()
     q.put((rank, info["epoch"], all(torch.equal(got[k], want[k]) for k in want), torch.equal(opt2.exp_avg[own], want_m[own]),
-           bool((stale_before - gathered_now).abs().max() > 0), int(opt2.step_dev.item())))
+           bool((stale_before - gathered_now).abs().max() > 0), int(opt2.step_dev.item()), guarded))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -244,8 +249,9 @@ def test_sharded_optimizer_checkpoint_resume_gloo(tmp_path, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, epoch, same_params, same_moments, was_stale, step_no in res:
+    for rank, epoch, same_params, same_moments, was_stale, step_no, guarded in res:
         assert epoch == 4 and step_no == 3
+        assert guarded, "state_dict() of a sharded optimizer without gather_state() must raise"
         assert was_stale, "the non-owned shard's moments were already current before the gather: the test checks nothing"
         assert same_params, f"rank {rank}: resumed run diverged from the uninterrupted one"
         assert same_moments, f"rank {rank}: resumed moments differ on the owned shard"

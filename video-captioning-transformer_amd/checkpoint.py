@@ -37,13 +37,15 @@ def _atomic_save(obj, path: str):
 
 def save_training_state(path: str, model, optimizer=None, scheduler=None, epoch: int = 0, early_stopping=None,
                         extra: Optional[dict] = None, write: bool = True):
-    """Data-parallel runs: EVERY rank calls this (a sharded optimizer all-gathers its Adam moments inside
-    optimizer.state_dict(): each rank only keeps the moments of the shards it owns current), and passes
-    write=(rank == 0) so that one rank writes the file."""
+    """Data-parallel runs: EVERY rank calls this (a sharded optimizer all-gathers its Adam moments first -- optimizer.gather_state(),
+    a collective: each rank only keeps the moments of the shards it owns current), and passes write=(rank == 0) so that one rank
+    builds the state dictionary and writes the file."""
     seed = getattr(model, "_seed", None)
-    opt_state = _to_cpu(optimizer.state_dict()) if optimizer is not None else None      # collective when sharded
+    if optimizer is not None and hasattr(optimizer, "gather_state"):
+        optimizer.gather_state()                         # collective when sharded; every rank
     if not write:
         return
+    opt_state = _to_cpu(optimizer.state_dict()) if optimizer is not None else None
     state = {
         "format": FORMAT,
         "model": {k: v.detach().cpu() for k, v in model.state_dict().items()},

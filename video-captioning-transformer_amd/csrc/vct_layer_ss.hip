@@ -99,7 +99,11 @@ struct SsLayerP {
 #endif
 };
 #ifdef SS_STAMPS
+#ifdef SS_STAMPS_ALLWAVES      /* every wave's lane 0: [B][8 waves][64] */
+#define SS_STAMP(i) do { if ((tid & 63) == 0) p.dbg[((long)blockIdx.x * 8 + (tid >> 6)) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
 #define SS_STAMP(i) do { if (tid == 0) p.dbg[(long)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
 #else
 #define SS_STAMP(i) do { } while (0)
 #endif
@@ -461,6 +465,9 @@ __global__ __launch_bounds__(SS_NT, SS_NW / 4) void layer_ss_fwd_kernel(const Ss
   float* red = reinterpret_cast<float*>(smem + SS_RED);
   float* b1s = reinterpret_cast<float*>(smem + SS_B1);
 
+  // (Waves 4-7 -- the second-dispatched half -- reach every barrier 3-6 k cycles behind waves 0-3: the older SIMD partner wins the
+  // issue arbitration.  s_setprio 1 for that half just swaps the roles, 264.6 vs 264.2 k cycles per decoder layer: zero-sum, as
+  // MI355X_MICROARCH.md says of two waves per SIMD.  tools/ss_layer_skew.hip.)
   WStream ws;
   ws.p = p.wpk + (long)wave * SS_WSTR + lane0 * 8;
   ws.last = ws.p + (long)(p.nchunks - 1) * SS_CHUNK;

@@ -673,14 +673,17 @@ def sync_wait(ident: int, stream=None):
     L.check(L.load().vct_sync_wait(int(ident), _sptr(stream)), "vct_sync_wait")
 
 
-_recording = False      # a LaunchList is recording on this thread (host-side collectives then go through host_call)
+import threading
+
+_rec = threading.local()     # .ll = the LaunchList recording on THIS thread (the C recorder is thread_local too): host-side collectives
+                             # issued on another thread while this one records run immediately, as they must
 
 
 def is_recording() -> bool:
-    return _recording
+    return getattr(_rec, "ll", None) is not None
 
 
-_host_fns = []          # CFUNCTYPE objects handed to vct_cmdlist_host_call: recorded lists call them for as long as they live
+_host_fns = []          # CFUNCTYPE objects of eager host calls made outside any recording (kept alive for the duration of the call only)
 
 
 def host_call(fn, stream=None):
@@ -696,7 +699,9 @@ def host_call(fn, stream=None):
             traceback.print_exc()
             return 1
     cfn = L.HOST_FN(thunk)
-    _host_fns.append(cfn)
+    ll = getattr(_rec, "ll", None)
+    if ll is not None:
+        ll._thunks.append(cfn)            # the recording owns its thunks (and the tensors they capture): released with the list
     L.check(L.load().vct_cmdlist_host_call(L.C.cast(cfn, L.vp), None, _sptr(stream)), "vct_cmdlist_host_call")
 
 
@@ -756,20 +761,20 @@ class LaunchList:
         h = L.vp()
         L.check(L.load().vct_cmdlist_create(L.C.byref(h)), "vct_cmdlist_create")
         self._h = h
+        self._thunks = []                 # host-call thunks of this recording (ops.host_call)
 
     class _Rec:
         def __init__(self, ll):
             self.ll = ll
 
         def __enter__(self):
-            global _recording
             L.check(L.load().vct_cmdlist_begin(self.ll._h, L.stream_ptr()), "vct_cmdlist_begin")
-            _recording = True
+            self.ll._thunks = []          # a re-recording replaces the commands, and with them the thunks they call
+            _rec.ll = self.ll
             return self.ll
 
         def __exit__(self, *exc):
-            global _recording
-            _recording = False
+            _rec.ll = None
             L.check(L.load().vct_cmdlist_end(self.ll._h), "vct_cmdlist_end")
             return False
 
@@ -790,6 +795,7 @@ class LaunchList:
         if self._h is not None and self._h.value:
             L.load().vct_cmdlist_destroy(self._h)
             self._h = None
+            self._thunks = []
 
     def __del__(self):
         try:

@@ -280,9 +280,19 @@ class FusedAdam(torch.optim.Optimizer):
         pass   # the backward schedule OVERWRITES every gradient (no accumulation across backward calls on the fast path)
 
     # ---- checkpointing (checkpoint.save_training_state): moments and step live outside torch's per-param state ----
-    def state_dict(self):
+    def gather_state(self):
+        """Data-parallel runs with a sharded optimizer: bring every rank's Adam moments up to date on this rank (a COLLECTIVE --
+        every rank calls it; checkpoint.save_training_state does).  No-op otherwise."""
         if self.pre_state_dict is not None:
             self.pre_state_dict()
+        self._gathered_at = int(self.step_dev.item())
+
+    def state_dict(self):
+        if self.pre_state_dict is not None and getattr(self, "_gathered_at", None) != int(self.step_dev.item()):
+            # the moments of the shards other ranks own are stale here: gathering them is a collective and must not hide in a call
+            # that a single rank may make (`if rank == 0: save(...)` would hang in it)
+            raise RuntimeError("FusedAdam.state_dict() under a sharded exchange: call optimizer.gather_state() on EVERY rank first "
+                               "(checkpoint.save_training_state does), then state_dict() on the rank(s) that write")
         sd = super().state_dict()
         ps = self.model._ps
         sd["vct_fused_adam"] = {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
