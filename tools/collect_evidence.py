@@ -18,8 +18,9 @@ def last_json(path):
 
 open(P("bench_n1.json"), "w").write(last_json(src + "bench_n1.json") + "\n")
 open(P("bench_profiled.json"), "w").write(last_json(src + "bench_profiled.json") + "\n")
-oc = [l for l in open(src + "other_configs.jsonl").read().splitlines() if l.startswith("{")]
-open(P("other_configs.jsonl"), "w").write("\n".join(oc) + "\n")
+if os.path.exists(src + "other_configs.jsonl"):      # (round 3: a separate tools/bench_configs.py run; since round 4 the bench line carries them)
+    oc = [l for l in open(src + "other_configs.jsonl").read().splitlines() if l.startswith("{")]
+    open(P("other_configs.jsonl"), "w").write("\n".join(oc) + "\n")
 shutil.copy(src + "pmc_per_kernel.txt", P("pmc_bench_per_kernel.txt"))
 shutil.copy(src + "gpu_tests.txt", P("gpu_tests.txt"))
 shutil.copy(src + "bench_list_kernel_summary.txt", P("bench_kernel_summary.txt"))
@@ -33,7 +34,8 @@ for l in open(src + "pmc_per_kernel.txt"):
         c = dict(kv.split("=") for kv in m.group(4).split())
         rows[m.group(1).strip()] = {"calls": int(m.group(2)), "avg_us": float(m.group(3)), **{k: float(v) for k, v in c.items()}}
 kb = lambda x: int(round(x * 1024))
-old = json.load(open(P("roofline_traffic.json")))
+prev = os.path.join("profiles", "r%02d_roofline_traffic.json" % (int(rnd[1:]) - 1))
+old = json.load(open(P("roofline_traffic.json") if os.path.exists(P("roofline_traffic.json")) else prev))   # kernel names / notes carried over
 
 
 def ent(key, name, alg):

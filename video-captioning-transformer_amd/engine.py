@@ -179,10 +179,13 @@ class ParamSet:
                 b = max(self.offsets[n] + self.params[n].numel() for n in names)
                 subs.append([a, b, blocks, True])
             ent = self.packed[key] = [t, firsts, subs]
+        todo = []
         for sub in ent[2]:
             if sub[3]:
-                ops.ss_pack(sub[2], ent[0])
+                todo += sub[2]
                 sub[3] = False
+        if todo:
+            ops.ss_pack(todo, ent[0])
         return ent[0], ent[1]
 
     def want_fragpack(self, name: str) -> torch.Tensor:
@@ -215,13 +218,16 @@ class ParamSet:
             if ent[3] and name not in skip and a <= ent[1] and ent[2] <= b:
                 ops.transpose(self.c[name], ent[0])
         for ent in self.packed.values():
+            todo = []
             for sub in ent[2]:
-                if sub[1] > a and sub[0] < b:                 # the rewritten range touches this layer
+                if sub[1] > a and sub[0] < b:                 # the rewritten range touches this part
                     if a <= sub[0] and sub[1] <= b:
-                        ops.ss_pack(sub[2], ent[0])
+                        todo += sub[2]
                         sub[3] = False
                     else:                                     # partly rewritten (no schedule does this): re-pack at the next use
                         sub[3] = True
+            if todo:
+                ops.ss_pack(todo, ent[0])                     # every part of the stack this pass rewrote: one launch (<= 48 blocks)
 
     def eager_transposed_in(self, a: int, b: int):
         """[(name, tensor, start, end)] of the eager transposed copies whose weight lies inside flat elements [a, b)."""
@@ -961,7 +967,11 @@ class DecoderEngine(_StackBase):
                 self.flush_dw(main=True)
                 if bucket_ready is not None:
                     self.flush_ln_grads(b)
-                    bucket_ready("dec_layer", l)
+                    # through the side stream like every other bucket: the hook's optimizer step REWRITES this layer's weights (and
+                    # their bf16 shadow), which the layer's d(memory) GEMM -- still queued on the side stream -- reads.  Handing the
+                    # bucket over from the main stream alone let Adam overtake that GEMM (found by the four-rank one-GPU test: wrong
+                    # encoder gradients / parameter updates on boxes where the side stream lagged)
+                    self.bucket_on_side(bucket_ready, "dec_layer", l)
                 self.flush_ln_grads(b)
                 ops.embed_bwd(ids, Sd, pad, dx, self.G("tgt_to_emb.weight"), dropout=self.drop(EMB_SITE),
                               exclusive=self.exclusive_grads and bucket_ready is None, on_grow=self._ws_grew)
