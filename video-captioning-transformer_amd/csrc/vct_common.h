@@ -10,6 +10,21 @@
 
 namespace vct {
 
+// Agent-scope (`sc1`) stores: written through the XCD's L2 without displacing what is resident there.  Measured on gfx950 with
+// FETCH_SIZE / TCC_EA0_RDREQ (tools/g256_traffic.sh, the 4864 x 30522 x 512 vocabulary projection): a plain store and a non-temporal
+// one (`nt`) both allocate in the write-back L2 and the 297 MB of logits evict the weight panels between two rounds of tiles (257 MB
+// fetched for 36 MB of operands); with these stores 141 MB.  The launch then ends only when the write-through has drained, which costs
+// more than the re-fetches (served by the memory-side cache) did -- an experiment switch (VCT_GEMM_NT=1), not a default.
+typedef __attribute__((ext_vector_type(4))) uint32_t stream_u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t stream_u32x2;
+__device__ __forceinline__ void store_stream16(void* dst, const stream_u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_stream8(void* dst, const stream_u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+}
+
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;

@@ -441,9 +441,11 @@ static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
   p.waves8 = pl.waves8;
   p.split = pl.split;
   {
-    static const char* env = getenv("VCT_GEMM_NT");          // A/B switch: 0 = never, 1 = always
-    const size_t out_bytes = (size_t)d->M * (size_t)d->N * (d->out_dtype == VCT_BF16 ? 2 : 4);
-    p.nt_store = env != nullptr ? (env[0] == '1') : (out_bytes > ((size_t)64 << 20));
+    // Output store policy (A/B switch VCT_GEMM_NT): 0 = plain (default), 1 = agent-scope streaming store (vct_common.h), 2 = `nt`.
+    // Round 4, same box, whole step: plain 2.243-2.252 ms, `nt` (the default until then for outputs > 64 MB) 2.252-2.265, agent scope
+    // 2.263-2.264 -- see the note at gemm256_try.
+    static const char* env = getenv("VCT_GEMM_NT");
+    p.nt_store = env != nullptr ? atoi(env) : 0;
   }
   {
     static const char* env = getenv("VCT_GEMM_NT_PREACT");   // A/B switch

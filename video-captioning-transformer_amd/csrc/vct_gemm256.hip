@@ -20,7 +20,7 @@
 //     zero-filling register path (tail_tile);
 //   * accumulators hold C transposed per MFMA tile (operands swapped), i.e. four consecutive COLUMNS per lane: the epilogue
 //     moves 8 / 16 bytes per LDS write into a row slab that lives in the stage just consumed, and every global store
-//     instruction writes whole 512-byte / 1-KB output rows (non-temporal for the 297 MB logits);
+//     instruction writes whole 512-byte / 1-KB output rows (plain write-back stores, see the note on the output store policy in gemm256_try);
 //   * XCD-aware order: the 32 workgroups of an XCD walk a contiguous run of work items with M fastest.
 // Measured at cfg-B (same box, tools/gen_fwd_bench.py): NT 176-186 us vs 234-250 us for the 128x128 kernel.  Ablation of the NT
 // form (VCT_GEMM256_DBG): operand DMA alone 82 us (26 B/clk/CU), MFMA + fragment reads alone 116 us, epilogue ~45 us = the
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
           if (ks == 0 && nx_dma) {        // (one per TWO row tiles over both k-steps: no better)
+            // (`nt` on either operand's loads: +10 us, same fetch traffic -- tools/g256_traffic.sh)
             if (i < TM / 2) dma_piece<A_MC, G256_BM, NW>(nb, p.A, p.lda, nx_m, p.M, nx_kt * BK2, wave, lane, i);
             else dma_piece<B_MC, G256_BN, NW>(nb + G256_BM * 128, p.B, p.ldb, nx_n, p.N, nx_kt * BK2, wave, lane, i - TM / 2);
           }
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256P p) {
         if (row < p.M && col < p.N) {
           TO* dst = (part ? reinterpret_cast<TO*>(pc) : reinterpret_cast<TO*>(p.C)) + (size_t)row * ldo + col;
           if (col + EPC <= p.N && (ldo % EPC) == 0) {
-            if (p.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+            if (p.nt_store == 1) store_stream16(dst, v);
+            else if (p.nt_store == 2) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
             else *reinterpret_cast<u32x4*>(dst) = v;
           } else {
             const TO* e = reinterpret_cast<const TO*>(&v);
@@ -318,8 +320,15 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   p.split = 1;
   const int nkt = (d->K + 63) / 64;
   p.kt_per_split = nkt;
-  p.nt_store = ((size_t)d->M * d->N * (d->out_dtype == VCT_BF16 ? 2 : 4) > ((size_t)64 << 20)) ? 1 : 0;
-  { static const char* ntenv = getenv("VCT_GEMM_NT"); if (ntenv != nullptr) p.nt_store = ntenv[0] == '1'; }
+  // Output store policy of the 297 MB of logits (VCT_GEMM_NT: 0 plain = default, 1 agent scope `sc1`, 2 `nt`).  Round 4, PMC passes
+  // (tools/g256_traffic.sh): plain and `nt` stores both allocate in the XCD's write-back L2, the logits evict the operand panels
+  // between two rounds of tiles, and every operand line is fetched once per round: 257 MB of reads for 36 MB of operands (L2 hit rate
+  // 0.69 = exactly "shared by the 4 / 8 workgroups of a round, nothing kept").  Agent-scope stores leave the panels alone: 141 MB of
+  // reads (total fabric traffic 438 MB = 1.31 x algorithmic), same time back to back (183 vs 185 us) -- but inside the step the
+  // launch then ends only when its write-through has drained: 0.207 ms against 0.178 (plain) / 0.183 (`nt`), whole step +20 us.
+  // The re-fetches come from the 256 MB memory-side cache, not from HBM; the time is what counts: plain stores.
+  p.nt_store = 0;
+  { static const char* ntenv = getenv("VCT_GEMM_NT"); if (ntenv != nullptr) p.nt_store = atoi(ntenv); }
   { static const char* oenv = getenv("VCT_GEMM256_ORDER"); p.order = oenv != nullptr ? atoi(oenv) : 1; }
   static const char* denv = getenv("VCT_GEMM256_DBG");
   p.dbg = denv != nullptr ? atoi(denv) : 0;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void dma_tile(unsigned char* lds, const bf16_t* __res
 }
 
 // instruction q (of R * 8 / (64 * NW) per wave) of dma_tile: one 1-KiB global_load_lds of an operand tile
-template <bool MC, int R, int NW>
+template <bool MC, int R, int NW, int AUX = 0>
 __device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int r0, int r_ext, int k0,
                                           int wave, int lane, int q) {
   const int ci = q * NW + wave;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void dma_piece(unsigned char* lds, const bf16_t* __re
     src = base + (long)(k0 + krow) * ld + min(r0 + col, rlim);
   }
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)(lds + ci * 1024), 16, 0, AUX);
 }
 
 // The same instruction with its per-lane source address split into a part that is fixed for a whole output tile (byte offset of the
@@ -448,7 +448,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   float* partC = part ? p.partial + (size_t)zid * (size_t)p.M * (size_t)p.N : nullptr;
   const long ldo = part ? (long)p.N : p.ldc;
   const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
-  const bool nt_store = p.nt_store != 0;
+  const int nt_store = p.nt_store;
   struct alignas(16) OutV { TO e[VO]; };
   // bias / activation (+ saved pre-activation) / activation derivative / dropout / residual-gradient accumulate on
   // VO consecutive columns of one row, then the store -- shared by the direct path and the in-kernel split-K reduce
@@ -471,16 +471,17 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         ov.e[q] = from_f<TO>(x[0]); ov.e[q + 1] = from_f<TO>(x[1]);
       }
       if (nt_store) {
-        // streaming-size output (logits): keep it out of the XCD's L2 so the operand tiles stay resident
+        // experiment switch (VCT_GEMM_NT): agent-scope / non-temporal output stores -- off by default, see vct_gemm.hip
         typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
+        if (nt_store == 1) store_stream16(C + (size_t)row * p.ldc + col, __builtin_bit_cast(u32x4, ov));
+        else __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(C + (size_t)row * p.ldc + col));
       } else {
         *reinterpret_cast<OutV*>(C + (size_t)row * p.ldc + col) = ov;
       }
       if (preact != nullptr) {
         if ((p.ld_preact % VO) == 0) {
           typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-          if (p.nt_preact) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, pv), reinterpret_cast<u32x4*>(preact + (size_t)row * p.ld_preact + col));
+          if (p.nt_preact) store_stream16(preact + (size_t)row * p.ld_preact + col, __builtin_bit_cast(u32x4, pv));
           else *reinterpret_cast<OutV*>(preact + (size_t)row * p.ld_preact + col) = pv;
         }
         else for (int q = 0; q < VO; q++) preact[(size_t)row * p.ld_preact + col + q] = pv.e[q];

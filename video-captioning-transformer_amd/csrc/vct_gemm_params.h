@@ -24,7 +24,7 @@ struct GemmP {
   int waves8;           // 128x128 tile with 8 waves (2x4) instead of 4 (2x2)
   int split;            // number of K splits (gridDim.z of the single launch)
   int* counters;        // != nullptr: per-tile arrival counters (zero on entry/exit): single-pass split-K
-  int nt_store;         // streaming-size output: non-temporal stores (keeps the operand tiles L2-resident)
+  int nt_store;         // output store policy: 0 plain, 1 agent-scope streaming (vct_common.h), 2 non-temporal (experiments; default 0)
   int nt_preact;        // the saved pre-activation is not read again before the backward: non-temporal stores
   int short_fast;       // tile order: the SHORTER tile dimension runs fastest (tiles sharing a K-long operand slab are neighbours)
 };

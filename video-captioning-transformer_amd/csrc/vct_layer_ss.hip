@@ -187,6 +187,10 @@ __device__ __forceinline__ void load_bias4(float4 (&bv)[SS_TPW], const float* bi
 
 struct alignas(8) BV4 { bf16_t e[4]; };
 struct alignas(16) BV8s { bf16_t e[8]; };
+// agent-scope streaming stores (vct_common.h) for the saved tensors: +1 % per layer (tools/ss_layer_stamps.hip, -DSS_STREAM_STORES=1): off
+#ifndef SS_STREAM_STORES
+#define SS_STREAM_STORES 0
+#endif
 
 // rows [0, rows) x NCOLS columns of an LDS panel -> global [row0 + r][col0 ..], 16 bytes per thread and step
 template <int NCOLS>
@@ -196,7 +200,11 @@ __device__ __forceinline__ void panel_to_global(const bf16_t* panel, const int p
   const int total = rows * vpr;
   for (int v = tid; v < total; v += SS_NT) {
     const int r = v / vpr, c = (v - r * vpr) * 8;
+#if SS_STREAM_STORES
+    store_stream16(g + (row0 + r) * ld + col0 + c, *reinterpret_cast<const stream_u32x4*>(panel + r * pstr + c));
+#else
     *reinterpret_cast<BV8s*>(g + (row0 + r) * ld + col0 + c) = *reinterpret_cast<const BV8s*>(panel + r * pstr + c);
+#endif
   }
 }
 // global rows -> panel (rows >= L zero-filled up to `alloc`)
@@ -276,6 +284,9 @@ __device__ __forceinline__ void epi_ln(f32x4 (&acc)[MT][SS_TPW], const float4 (&
     }
     part[m] = red4_sum(part[m]);
   }
+  // (Measured and dropped, round 4: ONE exchange of per-wave (sum, M2 about the wave's own mean) pairs combined exactly -- one barrier
+  // less per LayerNorm, 82.4 / 138.0 us per encoder / decoder layer against 82.4 / 135.7: the second barrier costs nothing once the
+  // waves are aligned by the first, the extra in-register pass does.)
   float* red0 = red;                  // [8][32]
   float* red1 = red + SS_NW * 32;
   auto stats = [&](float (&mean)[MT], float (&rstd)[MT]) {
@@ -710,7 +721,11 @@ __global__ __launch_bounds__(SS_NT, SS_NW / 4) void layer_ss_fwd_kernel(const Ss
           pv.e[0] = f2bf(acc[m][t][0] + bb.x); pv.e[1] = f2bf(acc[m][t][1] + bb.y);
           pv.e[2] = f2bf(acc[m][t][2] + bb.z); pv.e[3] = f2bf(acc[m][t][3] + bb.w);
           hpk[m][t] = pv;
+#if SS_STREAM_STORES
+          if (row < L) store_stream8(w.hpre + (grow0 + row) * p.ff + col, __builtin_bit_cast(stream_u32x2, pv));
+#else
           if (row < L) *reinterpret_cast<BV4*>(w.hpre + (grow0 + row) * p.ff + col) = pv;
+#endif
         }
     };
     auto ffn_tile = [&](const int j, auto K) {               // GELU + dropout of ONE 16 x 16 tile of chunk j -> activation panel
