@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 8
+#define VCT_ABI_VERSION 9
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -251,11 +251,41 @@ typedef struct vct_layer_ss_desc {
   const void* feats; void* x_in; const float* b_unify; const float* pe_rows;
   const int64_t* emb_ids; int64_t emb_ids_bs; const float* emb_table; const float* emb_pos;
 } vct_layer_ss_desc;
-typedef struct vct_ss_pack_seg { const void* w; int64_t ldw; int32_t nchunks; int32_t reserved; int64_t dst_chunk; } vct_ss_pack_seg;
+typedef struct vct_ss_pack_seg { const void* w; int64_t ldw; int32_t nchunks; int32_t transposed; int64_t dst_chunk; } vct_ss_pack_seg;
 int vct_layer_ss_supported(int dtype, int d, int H, int ff, int L, int Lm);
 int64_t vct_layer_ss_stream_chunks(int ff, int cross);
 int vct_ss_pack(const vct_ss_pack_seg* segs, int nseg, void* dst, void* stream);
 int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sample-stationary BACKWARD of a self-attention + feed-forward layer stack (the activation-gradient chain; bf16, d = 512, 8 heads,
+ * rows <= 32, <= 4 layers): ONE launch, one workgroup per sample, top layer first.
+ * replaces: the autograd nodes of nn.TransformerEncoder's layers between the gradient of the stack output and the gradient of the
+ * stack input (torch nn/modules/transformer.py:951-982 as built at MMEncoder.py:236-238): LayerNorm backward, linear2 / linear1 input
+ * gradients with GELU' and dropout, out_proj input gradient, attention backward, in_proj input gradient.  The weight gradients are
+ * NOT computed here: the kernel stores d f, d hpre, d a, d qkv (what vct_gemm_grouped multiplies with the saved activations) and one
+ * partial (dgamma | dbeta) row per sample and LayerNorm ([B][2][512] fp32, the layout vct_ln_param_finalize_batched sums).
+ * layers[0] is the TOP layer (last != 0: the stack-final norm is in front of it, y_last = that layer's output, dy = gradient of the
+ * normed output); layers[n-1].dx receives the gradient of the stack input.  wpk: the transposed weight blocks in stream order,
+ * vct_layer_ss_bwd_stream_chunks(ff) chunks per layer, layers back to back in processing order:
+ *   [linear2.weight^T block j (vct_ss_pack transposed segment: w = W2 + 512 j, ld = ff) | linear1.weight^T K slice j (w = W1 + 512 j * 512,
+ *    ld = 512)] for j < ff/512 | out_proj.weight^T (8 chunks) | in_proj_weight^T (24 chunks).
+ * x / qkv / a / x1 / hpre / f, the statistics and the dropout sites are the forward's (vct_layer_ss_desc: x, qkv, a, n1, hpre, f, n3).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_ss_bwd_norm { const float* gamma; const float* mean; const float* rstd; float* ws; } vct_ss_bwd_norm;
+typedef struct vct_layer_ss_bwd_desc {
+  int32_t dtype, B, L, d, H, ff, act, last, causal, key_pad_shift;
+  const void* wpk; int64_t nchunks;
+  const void* dy; void* dx; const void* y_last;
+  const void* x; const void* qkv; const void* a; const void* x1; const void* hpre; const void* f;
+  vct_ss_bwd_norm n1, n3, nf;
+  void* df; void* dhpre; void* da; void* dqkv;
+  const uint8_t* key_pad; const int64_t* key_ids; int64_t key_ids_bs; int64_t pad_id;
+  const uint32_t* seed; float p_drop;
+  uint32_t site_sa, site_n1, site_ff, site_n3;
+} vct_layer_ss_bwd_desc;
+int64_t vct_layer_ss_bwd_stream_chunks(int ff);
+int vct_layer_ss_bwd(const vct_layer_ss_bwd_desc* layers, int n_layers, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * y = LayerNorm(res + dropout(x)) (eps 1e-5, biased variance, affine); res may be NULL (plain LN).

@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 9
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -86,6 +86,8 @@ int main(void) {
          offsetof(vct_layer_ss_desc, key_pad), offsetof(vct_layer_ss_desc, site_n3), sizeof(vct_ss_pack_seg), offsetof(vct_ss_pack_seg, dst_chunk));
   printf("%zu %zu %zu %zu\\n", sizeof(vct_decode_bblock_desc), offsetof(vct_decode_bblock_desc, ids), offsetof(vct_decode_bblock_desc, w_a),
          offsetof(vct_decode_bblock_desc, ld_y));
+  printf("%zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_bwd_desc), offsetof(vct_layer_ss_bwd_desc, wpk), offsetof(vct_layer_ss_bwd_desc, n3),
+         offsetof(vct_layer_ss_bwd_desc, key_pad), offsetof(vct_layer_ss_bwd_desc, site_n3));
   return 0;
 }''')
     exe = tmp_path / "sz"
@@ -96,7 +98,9 @@ int main(void) {
     assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset,
                    ctypes.sizeof(S), S.wpk.offset, S.n2.offset, S.key_pad.offset, S.site_n3.offset, ctypes.sizeof(P), P.dst_chunk.offset,
                    ctypes.sizeof(_lib.DecodeBBlockDesc), _lib.DecodeBBlockDesc.ids.offset, _lib.DecodeBBlockDesc.w_a.offset,
-                   _lib.DecodeBBlockDesc.ld_y.offset]
+                   _lib.DecodeBBlockDesc.ld_y.offset,
+                   ctypes.sizeof(_lib.LayerSsBwdDesc), _lib.LayerSsBwdDesc.wpk.offset, _lib.LayerSsBwdDesc.n3.offset,
+                   _lib.LayerSsBwdDesc.key_pad.offset, _lib.LayerSsBwdDesc.site_n3.offset]
 
 
 def test_layer_ss_entry_points_validate_arguments(lib_path):
@@ -118,6 +122,15 @@ def test_layer_ss_entry_points_validate_arguments(lib_path):
     d.nchunks = 95
     assert lib.vct_layer_ss_fwd(d, 1, None) in (-1, -2)                            # (stream length does not match the layer)
     assert lib.vct_ss_pack(None, 1, None, None) == -1
+    # the backward of a self-attention + feed-forward stack (csrc/vct_layer_ss_bwd.hip)
+    assert lib.vct_layer_ss_bwd_stream_chunks(2048) == 96 and lib.vct_layer_ss_bwd_stream_chunks(512) == 48
+    assert lib.vct_layer_ss_bwd(None, 1, None) == -1
+    q = _lib.LayerSsBwdDesc()
+    q.dtype, q.B, q.L, q.d, q.H, q.ff, q.nchunks = _lib.BF16, 4, 13, 512, 8, 2048, 96
+    assert lib.vct_layer_ss_bwd(q, 1, None) == -1                                   # null operands
+    assert lib.vct_layer_ss_bwd(q, 5, None) == -2                                   # more layers than one launch carries
+    q.d = 768
+    assert lib.vct_layer_ss_bwd(q, 1, None) == -2
     # batched block decode (csrc/vct_decode_bblock.hip)
     assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 128, 30) == 1
     assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 4096, 128, 30) == 0 and lib.vct_decode_bblock_supported(_lib.BF16, 768, 8, 2048, 128, 30) == 0

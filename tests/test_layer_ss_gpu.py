@@ -137,6 +137,48 @@ def test_fused_equals_unfused_schedule(dropout):
     assert rel(g1, g0) < 3e-2
 
 
+@pytest.mark.parametrize("dropout,T", [(0.0, 12), (0.3, 12), (0.3, 15), (0.3, 20)])
+def test_fused_backward_equals_unfused_chain(dropout, T, monkeypatch):
+    """The encoder stack's activation-gradient chain as ONE launch (csrc/vct_layer_ss_bwd.hip) against the unfused kernels behind the
+    same forward: every gradient the weight-gradient GEMMs read (d f, d hpre, d a, d qkv), the gradient of the stack input and all
+    parameter gradients (LayerNorm partial rows included), with dropout ON (regenerated masks) and at 13 / 16 / 21 rows per sample."""
+    from vct_amd import engine, ops
+    V, B, S = 600, 7, 12
+    mc = _mc(enc=2, dec=1, ff=1024, dropout=dropout)
+    cfg = O.cfg_from_model_config(mc, V)
+    p = O.init_params(cfg, seed=11)
+    f, mk, ids = O.synthetic_batch(B, T, 512, S, V, seed=T, ragged=True)
+    feats, mask, idt = (torch.from_numpy(a).to(DEV) for a in (f, mk, ids))
+    calls = []
+    real = ops.layer_ss_bwd
+    monkeypatch.setattr(ops, "layer_ss_bwd", lambda descs: (calls.append(len(descs)), real(descs))[1])
+    runs = {}
+    old = engine._StackBase.fuse_bwd
+    try:
+        for fused in (True, False):
+            engine._StackBase.fuse_bwd = fused
+            m = build_model(mc, V, DEV, BF, p)
+            m.train(); m._seed.fill_(99)
+            m._forward_loss(feats, mask, idt, True)
+            m._backward()
+            e = m.video_encoder._engine().cur.t
+            def pick(k):     # (without dropout the unfused chain has no separate masked copy: it reads `ds`)
+                return e[k] if (fused or dropout > 0.0 or not k.endswith("dxo")) else e[k[:-3] + "ds"]
+            keep = {k: pick(k).float().clone() for k in ("L1.n2.dxo", "L1.ff.dhpre", "L1.n1.dxo", "L1.sa.dqkv", "L0.n2.dxo", "L0.ff.dhpre",
+                                                         "L0.n1.dxo", "L0.sa.dqkv", "L0.sa.dx")}
+            runs[fused] = (keep, m._ps.gflat.clone(), {k: m._ps.g[k].clone() for k in m._ps.g if k.startswith("video_encoder")})
+    finally:
+        engine._StackBase.fuse_bwd = old
+    assert calls == [2]                                      # one launch, two layers, in the fused run only
+    (k1, g1, e1), (k0, g0, e0) = runs[True], runs[False]
+    for k in k0:
+        assert rel(k1[k], k0[k]) < 2.5e-2, (k, rel(k1[k], k0[k]))
+    for k in e0:
+        if float(e0[k].float().norm()) > 1e-12:
+            assert rel(e1[k], e0[k]) < 3e-2, (k, rel(e1[k], e0[k]))
+    assert rel(g1, g0) < 2e-2
+
+
 def test_packed_stream_follows_the_weights():
     """Training steps through a recorded launch list (the optimizer rewrites the shadow, the pack launches behind it are part of the
     recording) and a load_state_dict in between: the fused forward must always see the current weights -- equal to the unfused

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -68,7 +68,21 @@ class LayerSsDesc(C.Structure):
 
 
 class SsPackSeg(C.Structure):
-    _fields_ = [("w", vp), ("ldw", i64), ("nchunks", i32), ("reserved", i32), ("dst_chunk", i64)]
+    _fields_ = [("w", vp), ("ldw", i64), ("nchunks", i32), ("transposed", i32), ("dst_chunk", i64)]
+
+
+class SsBwdNorm(C.Structure):
+    _fields_ = [("gamma", vp), ("mean", vp), ("rstd", vp), ("ws", vp)]
+
+
+class LayerSsBwdDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("B", i32), ("L", i32), ("d", i32), ("H", i32), ("ff", i32), ("act", i32), ("last", i32), ("causal", i32),
+                ("key_pad_shift", i32), ("wpk", vp), ("nchunks", i64), ("dy", vp), ("dx", vp), ("y_last", vp),
+                ("x", vp), ("qkv", vp), ("a", vp), ("x1", vp), ("hpre", vp), ("f", vp),
+                ("n1", SsBwdNorm), ("n3", SsBwdNorm), ("nf", SsBwdNorm),
+                ("df", vp), ("dhpre", vp), ("da", vp), ("dqkv", vp),
+                ("key_pad", vp), ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64), ("seed", vp), ("p_drop", f32),
+                ("site_sa", u32), ("site_n1", u32), ("site_ff", u32), ("site_n3", u32)]
 
 
 class DecodeGemvDesc(C.Structure):
@@ -120,6 +134,8 @@ _SIGS = {
     "vct_layer_ss_stream_chunks": (i64, [C.c_int, C.c_int]),
     "vct_ss_pack": (C.c_int, [C.POINTER(SsPackSeg), C.c_int, vp, vp]),
     "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), C.c_int, vp]),
+    "vct_layer_ss_bwd_stream_chunks": (i64, [C.c_int]),
+    "vct_layer_ss_bwd": (C.c_int, [C.POINTER(LayerSsBwdDesc), C.c_int, vp]),
     "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vct_linear_ln_fwd": (C.c_int, [C.POINTER(LinearLnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),

@@ -167,9 +167,9 @@ class ParamSet:
         if ent is None:
             parts, at, firsts = [], 0, []
             for names, blocks_fn in layers:
-                blocks = blocks_fn()
-                n = max(dc + nch for _w, nch, dc in blocks)
-                parts.append((names, [(w, nch, dc + at) for w, nch, dc in blocks]))
+                blocks = blocks_fn()                        # (w, nchunks, first chunk[, transposed])
+                n = max(blk[2] + blk[1] for blk in blocks)
+                parts.append((names, [(blk[0], blk[1], blk[2] + at) + tuple(blk[3:]) for blk in blocks]))
                 firsts.append(at)
                 at += n
             t = torch.empty(at * ops.SS_CHUNK, dtype=self.compute_dtype, device=self.device)
@@ -596,6 +596,67 @@ class _StackBase:
             parts.insert(0, ([self.pre + lead], lambda: [(self.ps.c[self.pre + lead][0:512], 8, 0)]))
         return self.ps.want_packed(self.pre + lps[0] + f"x{len(lps)}" + (lead or ""), parts)
 
+    def _ss_stream_bwd(self, lps):
+        """The packed TRANSPOSED weight stream of the self-attention + feed-forward layers `lps` (processing order of the backward:
+        top layer first) for vct_layer_ss_bwd: [linear2^T block j | linear1^T K slice j] x ff/512 | out_proj^T | in_proj^T."""
+        ff = self.cfg["ff"]
+
+        def one(lp):
+            P = self.pre + lp
+            names = [P + "self_attn.in_proj_weight", P + "self_attn.out_proj.weight", P + "linear1.weight", P + "linear2.weight"]
+
+            def blocks():
+                c, out, at = self.ps.c, [], 0
+                w1, w2 = c[P + "linear1.weight"], c[P + "linear2.weight"]
+                for j in range(ff // 512):
+                    out.append((w2[:, 512 * j:], 8, at, True)); at += 8
+                    out.append((w1[512 * j:512 * (j + 1)], 8, at, True)); at += 8
+                out.append((c[P + "self_attn.out_proj.weight"], 8, at, True)); at += 8
+                out.append((c[P + "self_attn.in_proj_weight"], 24, at, True)); at += 24
+                return out
+            return names, blocks
+        return self.ps.want_packed(self.pre + lps[0] + f"bwd{len(lps)}", [one(lp) for lp in lps])
+
+    # A/B switch: the activation-gradient chain of a self-attention + feed-forward stack as ONE launch (csrc/vct_layer_ss_bwd.hip)
+    fuse_bwd = os.environ.get("VCT_FUSE_BWD", "1") != "0"
+
+    def _stack_ss_bwd(self, b, lps, tags, sites0, dy, dx, Bn, Lr, *, ln_tag, ln_name, final, kpm=None, causal=False):
+        """Gradient of the stack input from the gradient `dy` of the (final-normed) stack output: ONE launch; queues the layers' weight-
+        gradient GEMMs (grouped, one launch per layer) and the LayerNorm parameter partials behind it.  lps / tags / sites0 in FORWARD
+        order (bottom layer first)."""
+        d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
+        M = Bn * Lr
+        f32 = torch.float32
+        order = list(reversed(range(len(lps))))
+        wpk, firsts = self._ss_stream_bwd([lps[l] for l in order])
+        per = ops.layer_ss_bwd_stream_chunks(ff)
+        descs, after = [], []
+        for k, l in enumerate(order):
+            lp, tag, site = lps[l], tags[l], sites0[l]
+
+            def nb(t, name):
+                ws = b.get(t + "ss_ws", (Bn * 2 * d,), f32)
+                self._ln_pending.append((ws.data_ptr(), self.G(name + "weight").data_ptr(), self.G(name + "bias").data_ptr(), Bn))
+                return (self.F(name + "weight"), b.t[t + "mean"], b.t[t + "rstd"], ws)
+            nf = nb("nf.", final) if k == 0 else None
+            n3 = nb(tag + ln_tag, lp + ln_name)
+            n1 = nb(tag + "n1.", lp + "norm1.")
+            df, dhpre = b.get(tag + ln_tag + "dxo", (M, d), self.dt), b.get(tag + "ff.dhpre", (M, ff), self.dt)
+            da, dqkv = b.get(tag + "n1.dxo", (M, d), self.dt), b.get(tag + "sa.dqkv", (M, 3 * d), self.dt)
+            x, x1 = b.t[tag + "x"], b.t[tag + "n1.y"]
+            descs.append(ops.layer_ss_bwd_desc(
+                B=Bn, Lr=Lr, wpk=wpk[firsts[k] * ops.SS_CHUNK:], nchunks=per, ff=ff, act=self.cfg["activation"], H=H,
+                x=x, qkv=b.t[tag + "sa.qkv"], a=b.t[tag + "sa.a"], x1=x1, hpre=b.t[tag + "ff.hpre"], f=b.t[tag + "ff.f"],
+                n1=n1, n3=n3, nf=nf, y_last=b.t["x_last"] if k == 0 else None, dy=dy if k == 0 else None,
+                dx=dx if k == len(order) - 1 else None, outs=(df, dhpre, da, dqkv),
+                sites=(site + 1, site + 2, site + 3, site + 4), causal=causal, key_pad=kpm,
+                seed=self.seed if self.p_drop > 0.0 else None, p_drop=self.p_drop))
+            sa = lp + "self_attn."
+            after.append([(df, b.t[tag + "ff.h"], lp + "linear2."), (dhpre, x1, lp + "linear1."), (da, b.t[tag + "sa.o"], sa + "out_proj."),
+                          (dqkv, x, sa + "in_proj_")])
+        ops.layer_ss_bwd(descs)
+        return order, after
+
     def _stack_ss(self, b, lps, tags, x, Bn, Lr, sites0, *, ln_tag, ln_name, final, mem=None, Lm=0, causal=False, kpm=None,
                   frontend=None, embed=None):
         """The layers `lps` (buffer tags `tags`, dropout site bases `sites0`) on input x [Bn*Lr, d] in ONE launch per four layers.
@@ -746,6 +807,27 @@ class EncoderEngine(_StackBase):
         B, T = self.shape
         Te, L = T + 1, self.cfg["layers"]
         kpm = b.t["kpm_used"]
+        if self.fuse_bwd and self._ss_ok(Te, 0, B) and L <= 4 and dmem.dtype == self.dt:
+            # the whole dX chain of the stack in one launch; behind it one grouped weight-gradient launch per layer
+            dx = b.get("L0.sa.dx", (B * Te, self.cfg["d"]), self.dt)
+            order, after = self._stack_ss_bwd(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)],
+                                              [ENC_SITE + 16 * l for l in range(L)], dmem, dx, B, Te, ln_tag="n2.", ln_name="norm2.",
+                                              final="transformer_encoder.norm.", kpm=kpm)
+            for l, items in zip(order, after):
+                for dyv, xv, name in items:
+                    self.dw_gemm(dyv, xv, self.G(name + "weight"), bias_grad=self.G(name + "bias"))
+                if l > 0:
+                    self.flush_dw()
+                if bucket_ready is not None and l > 0:
+                    self.flush_ln_grads(b)
+                    self.bucket_on_side(bucket_ready, "enc_layer", l)
+            du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
+            self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), bias_grad=self.G("unify.0.bias"))
+            self.flush_ln_grads(b)
+            self.join_side()
+            if bucket_ready is not None:
+                bucket_ready("enc_layer", 0)
+            return
         dx, _ = self._ln_bwd(b, "nf.", "transformer_encoder.norm.", dmem, b.t["x_last"], None, None)
         for l in reversed(range(L)):
             lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l

@@ -215,11 +215,60 @@ def ss_pack(blocks, dst: torch.Tensor):
     `dst` (bf16, stream order: include/vct_hip.h, vct_ss_pack).  One launch per 48 blocks."""
     n = len(blocks)
     segs = (L.SsPackSeg * n)()
-    for i, (w, nch, dc) in enumerate(blocks):
-        assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and w.shape[0] >= 512 and w.shape[1] >= 64 * nch
+    for i, blk in enumerate(blocks):
+        w, nch, dc = blk[:3]
+        tr = bool(blk[3]) if len(blk) > 3 else False        # transposed block: element (n, k) of the stream's matrix is w[k][n]
+        if tr:
+            assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and w.shape[1] >= 512 and w.shape[0] >= 64 * nch
+        else:
+            assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and w.shape[0] >= 512 and w.shape[1] >= 64 * nch
         segs[i].w, segs[i].ldw, segs[i].nchunks, segs[i].dst_chunk = w.data_ptr(), w.stride(0), int(nch), int(dc)
+        segs[i].transposed = int(tr)
     L.check(L.load().vct_ss_pack(segs, n, dst.data_ptr(), L.stream_ptr()), "vct_ss_pack")
     return dst
+
+
+def layer_ss_bwd_stream_chunks(ff: int) -> int:
+    return int(L.load().vct_layer_ss_bwd_stream_chunks(int(ff)))
+
+
+def layer_ss_bwd_desc(*, B, Lr, wpk, nchunks, ff, act, H, x, qkv, a, x1, hpre, f, n1, n3, outs, sites, nf=None, y_last=None, dy=None, dx=None,
+                      causal=False, key_pad=None, seed=None, p_drop=0.0):
+    """Descriptor of ONE layer of a sample-stationary backward launch (include/vct_hip.h, vct_layer_ss_bwd_desc).  nX = (gamma, mean,
+    rstd, ws[B, 2, 512] fp32); outs = (df, dhpre, da, dqkv); sites = (self-attention probabilities, norm1, feed-forward, last norm)."""
+    q = L.LayerSsBwdDesc()
+    q.dtype, q.B, q.L, q.d, q.H, q.ff, q.act = L.BF16, int(B), int(Lr), x.shape[1], int(H), int(ff), L.ACT[act]
+    q.last, q.causal = int(nf is not None), int(causal)
+    q.wpk, q.nchunks = wpk.data_ptr(), int(nchunks)
+    q.dy, q.dx, q.y_last = L.ptr(dy), L.ptr(dx), L.ptr(y_last)
+    q.x, q.qkv, q.a, q.x1, q.hpre, q.f = (t.data_ptr() for t in (x, qkv, a, x1, hpre, f))
+
+    def norm(dst, t):
+        dst.gamma, dst.mean, dst.rstd, dst.ws = (z.data_ptr() for z in t)
+    norm(q.n1, n1)
+    norm(q.n3, n3)
+    if nf is not None:
+        norm(q.nf, nf)
+    q.df, q.dhpre, q.da, q.dqkv = (t.data_ptr() for t in outs)
+    q.key_pad_shift = 0
+    if isinstance(key_pad, tuple) and key_pad[0] == "ids":
+        _tag, ids, pad_id = key_pad
+        q.key_ids, q.key_ids_bs, q.pad_id = ids.data_ptr(), ids.stride(0), int(pad_id)
+    elif isinstance(key_pad, tuple):
+        m, shift = key_pad
+        q.key_pad, q.key_pad_shift = m.data_ptr(), int(shift)
+    elif key_pad is not None:
+        q.key_pad = key_pad.data_ptr()
+    q.seed, q.p_drop = L.ptr(seed), float(p_drop)
+    q.site_sa, q.site_n1, q.site_ff, q.site_n3 = (int(z) for z in sites)
+    return q
+
+
+def layer_ss_bwd(descs):
+    """One launch: the activation-gradient chain of a self-attention + feed-forward stack, descs[0] = the TOP layer."""
+    n = len(descs)
+    arr = (L.LayerSsBwdDesc * n)(*descs)
+    L.check(L.load().vct_layer_ss_bwd(arr, n, L.stream_ptr()), "vct_layer_ss_bwd")
 
 
 def layer_ss_desc(*, B, Lr, x, wpk, nchunks, ff, act, H, bias, sa, n1, ffn, n3, cross=None, n2=None, nf=None, mem=None, Lm=0,
