@@ -617,8 +617,12 @@ class _StackBase:
             return names, blocks
         return self.ps.want_packed(self.pre + lps[0] + f"bwd{len(lps)}", [one(lp) for lp in lps])
 
-    # A/B switch: the activation-gradient chain of a self-attention + feed-forward stack as ONE launch (csrc/vct_layer_ss_bwd.hip)
-    fuse_bwd = os.environ.get("VCT_FUSE_BWD", "1") != "0"
+    # The activation-gradient chain of a self-attention + feed-forward stack as ONE launch (csrc/vct_layer_ss_bwd.hip): OFF by default.
+    # Measured at cfg-B (round 4, same box): the launch takes 236 us ALONE for the two encoder layers against 253 us for the 14 unfused
+    # launches alone -- but it takes whole compute units (152 KB of LDS per workgroup), so nothing runs beside it, while the unfused
+    # chain shares the chip with the vocabulary weight gradient and the optimizer's pass in the step's tail: step 2.40-2.42 ms with it
+    # (beside the tail, or alone on the main stream ahead of the optimizer) against 2.24-2.26 ms without.  VCT_FUSE_BWD=1 enables it.
+    fuse_bwd = os.environ.get("VCT_FUSE_BWD", "0") == "1"
 
     def _stack_ss_bwd(self, b, lps, tags, sites0, dy, dx, Bn, Lr, *, ln_tag, ln_name, final, kpm=None, causal=False):
         """Gradient of the stack input from the gradient `dy` of the (final-normed) stack output: ONE launch; queues the layers' weight-
@@ -802,12 +806,19 @@ class EncoderEngine(_StackBase):
         b.t["x_last"] = x
         return self._ln_fwd(b, "nf.", "transformer_encoder.norm.", x, None, None)
 
-    def backward(self, dmem: torch.Tensor, bucket_ready=None):
+    def ss_bwd_ok(self) -> bool:
+        """The current shape's activation-gradient chain runs as one sample-stationary launch (csrc/vct_layer_ss_bwd.hip)."""
+        B, T = self.shape
+        return bool(self.fuse_bwd and self._ss_ok(T + 1, 0, B) and self.cfg["layers"] <= 4)
+
+    def backward(self, dmem: torch.Tensor, bucket_ready=None, join: bool = True):
+        """join = False (one-launch backward on the main stream, trainer): the weight-gradient GEMMs stay un-joined on the side
+        stream; the caller joins before it touches the encoder's gradients."""
         b = self.cur
         B, T = self.shape
         Te, L = T + 1, self.cfg["layers"]
         kpm = b.t["kpm_used"]
-        if self.fuse_bwd and self._ss_ok(Te, 0, B) and L <= 4 and dmem.dtype == self.dt:
+        if self.ss_bwd_ok() and dmem.dtype == self.dt:
             # the whole dX chain of the stack in one launch; behind it one grouped weight-gradient launch per layer
             dx = b.get("L0.sa.dx", (B * Te, self.cfg["d"]), self.dt)
             order, after = self._stack_ss_bwd(b, [f"transformer_encoder.layers.{l}." for l in range(L)], [f"L{l}." for l in range(L)],
@@ -824,7 +835,10 @@ class EncoderEngine(_StackBase):
             du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
             self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), bias_grad=self.G("unify.0.bias"))
             self.flush_ln_grads(b)
-            self.join_side()
+            if join or bucket_ready is not None:
+                self.join_side()
+            else:
+                self.flush_dw()
             if bucket_ready is not None:
                 bucket_ready("enc_layer", 0)
             return

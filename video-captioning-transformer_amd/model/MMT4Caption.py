@@ -172,10 +172,16 @@ class MMT4Caption(nn.Module):
         self.launch_encoder_backward()
         self.cap_decoder._engine().join_side()
 
-    def launch_encoder_backward(self):
+    def launch_encoder_backward(self, main: bool = False):
+        """main: enqueue it on the CURRENT stream (the caller has joined the side stream: d(memory) is final) -- for the one-launch
+        sample-stationary backward, which takes whole compute units and gains nothing from running beside other kernels."""
         fn, self._pending_enc_bwd = getattr(self, "_pending_enc_bwd", None), None
         if fn is not None:
-            fn()
+            fn(main)
+
+    def encoder_backward_is_one_launch(self) -> bool:
+        enc = self.video_encoder._engine()
+        return enc.ss_bwd_ok()
 
     def _backward(self, bucket_ready=None, join: bool = True):
         hook = None
@@ -186,7 +192,10 @@ class MMT4Caption(nn.Module):
         if self.overlap_enc_bwd and dec.dev.type == "cuda" and dec.overlap_dw:
             # the encoder's backward only needs d(memory): it runs on the side stream beside the decoder's bottom
             # self-attention backward and the embedding gradient (two chains of small kernels share the chip)
-            def launch(dmem, dmem_point):
+            def launch(dmem, dmem_point, main=False):
+                if main:
+                    enc.backward(dmem, hook, join=False)
+                    return
                 side = dec.ensure_side()
                 ops.sync_wait(dmem_point, side)                   # d(memory) final (its last accumulate is on `side` itself)
                 with torch.cuda.stream(side):
@@ -196,7 +205,7 @@ class MMT4Caption(nn.Module):
                 if join:
                     launch(dmem, dmem_point)
                 else:      # the caller enqueues its own main-stream work first (the host launches ~35 kernels here)
-                    self._pending_enc_bwd = lambda: launch(dmem, dmem_point)
+                    self._pending_enc_bwd = lambda main=False: launch(dmem, dmem_point, main)
             dec.backward(hook, on_dmem_ready=on_dmem, join=join)  # join: ends with the main stream joining the side stream
         else:
             dmem = dec.backward(hook)

@@ -432,6 +432,10 @@ class CaptionTrainer:
             # those gradients and rewrites the weights those kernels read, so the main stream joins the side stream first
             # (it is idle here: the encoder backward has not been enqueued yet)
             m.cap_decoder._engine().join_side()
+            if m.encoder_backward_is_one_launch():
+                # the sample-stationary backward takes whole compute units: alone on the main stream, ahead of the optimizer's pass; its
+                # weight-gradient GEMMs (side stream) then run beside that pass
+                m.launch_encoder_backward(main=True)
             ops.tap("adam", 0)
             self.opt.step_range(0, a)            # enqueued BEFORE the encoder backward: one launch vs ~35
             ops.tap("adam", 1)
