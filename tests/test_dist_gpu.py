@@ -98,30 +98,6 @@ def _worker(rank, world, port, dtype_name, q, sharded=False, executor="eager", c
             g_first = m.flat_grads.detach().double().cpu().numpy()
     torch.cuda.synchronize()
     ok_oracle, why = True, []
-    if os.environ.get("VCT_DEBUG_RANKS") and check_oracle:
-        # which ranks' contribution is wrong?  local (no exchange) gradients of step 1 on the start parameters, gathered
-        import numpy as np
-        keep = m.flat_params.clone()
-        m.flat_params.copy_(start); m._ps.refresh_shadow(force=True)
-        m.train_step_kernels(*_batch(10 + rank, dev)); torch.cuda.synchronize()
-        loc = m.flat_grads.clone()
-        allg = [torch.empty_like(loc) for _ in range(world)]
-        dist.all_gather(allg, loc)
-        allg = [x.double().cpu().numpy() for x in allg]
-        bk = m.grad_buckets()
-        a2, b2 = bk[2]
-        a1, b1 = bk[1]
-        mean = sum(allg) / world
-        msg = ["b2 err vs hip mean %.4f" % (np.linalg.norm(g_first[a2:b2] - mean[a2:b2]) / np.linalg.norm(mean[a2:b2]))]
-        for r in range(world):
-            alt = (sum(allg) - allg[r]) / world
-            msg.append("drop%d %.4f" % (r, np.linalg.norm(g_first[a2:b2] - alt[a2:b2]) / np.linalg.norm(mean[a2:b2])))
-        for r in range(world):
-            for q2 in range(r + 1, world):
-                alt = (sum(allg) - allg[r] - allg[q2]) / world
-                msg.append("drop%d%d %.4f" % (r, q2, np.linalg.norm(g_first[a2:b2] - alt[a2:b2]) / np.linalg.norm(mean[a2:b2])))
-        why.append(" ".join(msg))
-        m.flat_params.copy_(keep); m._ps.refresh_shadow(force=True)
     if check_oracle:
         # exchanged HIP step vs the CPU oracle: (a) the averaged gradient this rank holds after step 1 (its own shard of every
         # bucket when sharded, everything otherwise) within 1e-3 per bucket -- Adam is scale-invariant, so a wrong 1/world only
