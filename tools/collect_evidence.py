@@ -41,7 +41,7 @@ old = json.load(open(P("roofline_traffic.json") if os.path.exists(P("roofline_tr
 def ent(key, name, alg):
     r = rows[key]
     f, w = kb(r["FETCH_SIZE"] * 2), kb(r["WRITE_SIZE"])
-    return {"kernel": old[name]["kernel"], "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "algorithmic_min_bytes": alg,
+    return {"kernel": key.split(" [")[0].strip(), "what": old.get(name, {}).get("what", old.get(name, {}).get("kernel", name)), "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "algorithmic_min_bytes": alg,
             "avg_us_profiled": r["avg_us"], "l2_hit_rate": round(r["TCC_HIT"] / (r["TCC_HIT"] + r["TCC_MISS"]), 3),
             "mfma_busy_cycles": r["SQ_VALU_MFMA_BUSY_CYCLES"], "gui_active_cycles": r["GRBM_GUI_ACTIVE"]}
 
@@ -63,7 +63,11 @@ out = {"_source": old["_source"].split("calibrated in the same run")[0] +
        "gen_fwd": ent(find("gemm256_kernel<0, 1, bf16>"), "gen_fwd", 333000000), "gen_dx": dx,
        "gen_dw": ent(find("gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 364500000),
        "sce_loss": ent(find("sce_loss_kernel<bf16"), "sce_loss", 593952768), "adam": ent(find("adam_kernel"), "adam", 0),
-       "adam2d": ent(find("adam2d_kernel"), "adam2d", 0), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048))}
+       "adam2d": ent(find("adam2d_kernel"), "adam2d", 0), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048)),
+       # the sample-stationary stacks: every workgroup streams all of the stack's weights through its XCD's L2 (algorithmic = the
+       # weights once + the features / ids read + the tensors saved for the backward)
+       "enc_stack_fwd": ent(find("layer_ss_fwd_kernel<false"), "encoder stack forward (2 layers + front end), one launch", 0),
+       "dec_stack_fwd": ent(find("layer_ss_fwd_kernel<true"), "decoder stack forward (2 layers + embedding), one launch", 0)}
 json.dump(out, open(P("roofline_traffic.json"), "w"), indent=1)
 d = json.loads(last_json(src + "bench_n1.json"))
 print(f"{d['value']:.0f} samples/s, {d['ms_per_step']} ms/step; roofline {d['roofline']['kernel_tag']} {d['roofline']['frac']}; "
