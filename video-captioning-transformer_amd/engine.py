@@ -1056,11 +1056,11 @@ class DecoderEngine(_StackBase):
                 ops.sync_record(dmem_point)
                 # the bottom layer's weight gradients run on the MAIN stream (whose tail is not the critical path any
                 # more): the side stream is free for the encoder backward the moment d(memory) is final
-                self.flush_dw(main=True)
+                self.flush_dw(main=self.l0_dw_main & 1 != 0)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
             if l == 0 and on_dmem_ready is not None:
-                self.flush_dw(main=True)
+                self.flush_dw(main=self.l0_dw_main & 2 != 0)
                 if bucket_ready is not None:
                     self.flush_ln_grads(b)
                     # through the side stream like every other bucket: the hook's optimizer step REWRITES this layer's weights (and
@@ -1406,6 +1406,8 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
 DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "1") != "0"
 DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
+# bit 0 / bit 1: the bottom decoder layer's cross-attention + feed-forward / self-attention weight gradients on the MAIN stream (A/B)
+DecoderEngine.l0_dw_main = int(os.environ.get("VCT_L0_DW_MAIN", "3"))
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 
