@@ -16,5 +16,5 @@ bash tools/prof_step.sh $TAG
 bash tools/pmc_bench.sh $OUT/pmc > /dev/null 2>&1
 python tools/pmc_bench_summary.py $OUT/pmc > $OUT/pmc_per_kernel.txt 2>&1
 rm -rf $OUT/pmc/bench_*/x_counter_collection.csv $OUT/pmc/bench_*/x_kernel_trace.csv 2>/dev/null
-python -m pytest tests -q -m gpu 2>&1 | tail -4 > $OUT/gpu_tests.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $OUT/gpu_tests.txt
 tail -2 $OUT/gpu_tests.txt; tail -c 400 $OUT/bench_n1.json
