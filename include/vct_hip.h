@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 9
+#define VCT_ABI_VERSION 10
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -386,6 +386,15 @@ int vct_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   const float* hyper_dev, void* stream);
 /* The same step over ONE 2-D weight [rows, cols] (cols a multiple of 64; contiguous) that also writes its TRANSPOSED bf16 shadow
  * shadow_t [cols][ld_t >= rows] -- W_g^T for the NT form of the vocabulary dX -- in the same pass (no step-counter bump). */
+/* vct_adam_step that ALSO writes the stream-order packed copies (vct_ss_pack layout) of the weight matrices listed in segs_dev
+ * (device array, sorted by `begin`; flat element indices of the WHOLE parameter buffer, `base` = index of param[0] in it):
+ * mode 0 = the matrix [N, K] is packed as 512-row blocks, block i at chunk chunk0[i]; mode 1 = a 512-row matrix packed as 512-column
+ * K slices, slice i at chunk0[i] (chunk0 < 0: not packed).  No reference counterpart (a layout copy refreshed with the shadow). */
+typedef struct vct_adam_pack_seg { int64_t begin, end; int32_t K, mode; int32_t chunk0[4]; void* stream; } vct_adam_pack_seg;
+int vct_adam_step_pk(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
+                     const float* hyper_dev, const vct_adam_pack_seg* segs_dev, int32_t nseg, int64_t base, void* stream);
 int vct_adam_step_2d(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                      void* shadow_t_bf16, int32_t rows, int32_t cols, int64_t ld_t, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t* step_dev, const float* hyper_dev, void* stream);

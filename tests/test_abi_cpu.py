@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 10
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -131,6 +131,13 @@ def test_layer_ss_entry_points_validate_arguments(lib_path):
     assert lib.vct_layer_ss_bwd(q, 5, None) == -2                                   # more layers than one launch carries
     q.d = 768
     assert lib.vct_layer_ss_bwd(q, 1, None) == -2
+    # Adam that also maintains stream-order packed weight copies: a table without a shadow / a misaligned base are argument errors
+    assert ctypes.sizeof(_lib.AdamPackSeg) == 48
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.addressof(buf)
+    assert lib.vct_adam_step_pk(p, p, p, p, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, p, 1, 0, None) == -1
+    assert lib.vct_adam_step_pk(p, p, p, p, p, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, p, 1, 2, None) == -1
+    assert lib.vct_adam_step_pk(p, p, p, p, p, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, None, -1, 0, None) == -1
     # batched block decode (csrc/vct_decode_bblock.hip)
     assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 128, 30) == 1
     assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 4096, 128, 30) == 0 and lib.vct_decode_bblock_supported(_lib.BF16, 768, 8, 2048, 128, 30) == 0

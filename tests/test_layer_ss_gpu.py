@@ -205,6 +205,13 @@ def test_packed_stream_follows_the_weights():
                 losses.append(float(tr.step(fe, mk, ii)))
             torch.cuda.synchronize()
             out[fused] = (losses, m.flat_params.clone())
+            if fused:      # the packed streams the optimizer's pass maintains == a fresh vct_ss_pack of the current shadow, bit for bit
+                from vct_amd import ops
+                assert m._ps.packed
+                for key, (stream, _firsts, subs) in m._ps.packed.items():
+                    fresh = ops.ss_pack([blk for sub in subs for blk in sub[2]], torch.zeros_like(stream))
+                    torch.cuda.synchronize()
+                    assert torch.equal(fresh.view(torch.int16), stream.view(torch.int16)), key
     finally:
         _fuse(old)
     for a, b in zip(out[True][0], out[False][0]):

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -69,6 +69,10 @@ class LayerSsDesc(C.Structure):
 
 class SsPackSeg(C.Structure):
     _fields_ = [("w", vp), ("ldw", i64), ("nchunks", i32), ("transposed", i32), ("dst_chunk", i64)]
+
+
+class AdamPackSeg(C.Structure):
+    _fields_ = [("begin", i64), ("end", i64), ("K", i32), ("mode", i32), ("chunk0", i32 * 4), ("stream", vp)]
 
 
 class SsBwdNorm(C.Structure):
@@ -163,6 +167,7 @@ _SIGS = {
     "vct_greedy_select": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, i64, vp, vp, vp, i32, vp]),
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp]),
+    "vct_adam_step_pk": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp, C.c_int, i64, vp]),
     "vct_adam_step_2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
     "vct_cmdlist_create": (C.c_int, [C.POINTER(vp)]),
     "vct_cmdlist_destroy": (C.c_int, [vp]),

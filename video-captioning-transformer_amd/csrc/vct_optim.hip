@@ -8,10 +8,17 @@
 
 namespace vct {
 
+// A weight matrix [N, K] at flat elements [begin, end) that has a stream-order packed copy (vct_ss_pack: the sample-stationary
+// stack kernels' operand): mode 0 = packed as 512-ROW blocks (block r / 512 starts at chunk chunk0[r / 512]), mode 1 = packed as
+// 512-COLUMN K slices of a 512-row matrix (slice c / 512 at chunk0[c / 512]).  The optimizer's pass writes the packed copy with the
+// shadow: +2 B per parameter instead of a pack launch (read + write of the stream) behind it on the step's critical path.
+struct AdamPackSeg { int64_t begin, end; int32_t K, mode; int32_t chunk0[4]; bf16_t* stream; };
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, const int32_t* __restrict__ step,
-                                                   int64_t skip_a, int64_t skip_b, const float* __restrict__ hyper) {
+                                                   int64_t skip_a, int64_t skip_b, const float* __restrict__ hyper,
+                                                   const AdamPackSeg* __restrict__ segs, int nseg, int64_t base) {
   // hyper-parameters from DEVICE memory when given: a captured hipGraph / recorded launch list then follows the
   // learning-rate schedule (kernel arguments are frozen at capture time)
   if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
@@ -44,6 +51,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       ushort4 o;
       o.x = f2bf(pv.x); o.y = f2bf(pv.y); o.z = f2bf(pv.z); o.w = f2bf(pv.w);
       reinterpret_cast<ushort4*>(shadow)[i] = o;
+      if (nseg > 0) {
+        const int64_t ef = base + e;
+        int lo = 0, hi = nseg;                               // last segment that begins at or before ef (sorted by begin)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (segs[mid].begin <= ef) lo = mid; else hi = mid; }
+        const AdamPackSeg sg = segs[lo];
+        if (ef >= sg.begin && ef < sg.end) {
+          const int64_t rel = ef - sg.begin;
+          const int r = (int)(rel / sg.K), c = (int)(rel - (int64_t)r * sg.K);
+          const int blk = sg.mode == 0 ? (r >> 9) : (c >> 9);
+          const int nn = sg.mode == 0 ? (r & 511) : r, kk = sg.mode == 0 ? c : (c & 511);
+          const int ch0 = sg.chunk0[blk & 3];
+          if (blk < 4 && ch0 >= 0) {
+            // chunk = 64 columns of K; inside: wave nn / 64, tile (nn % 64) / 16, k-step, then lane = (k group, row % 16), 8 bf16 each
+            const int64_t vec = (int64_t)(ch0 + (kk >> 6)) * 4096 + (((nn >> 6) * 8 + ((nn & 63) >> 4) * 2 + ((kk & 63) >> 5)) * 64 +
+                                                                      ((kk & 31) >> 3) * 16 + (nn & 15));
+            *reinterpret_cast<ushort4*>(sg.stream + vec * 8 + (kk & 7)) = o;
+          }
+        }
+      }
     }
   }
 }
@@ -123,6 +149,16 @@ extern "C" int vct_adam_step(float* param, const float* grad, float* exp_avg, fl
                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                              int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
                              const float* hyper_dev, void* stream) {
+  return vct_adam_step_pk(param, grad, exp_avg, exp_avg_sq, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin,
+                          shadow_skip_end, bump_step, hyper_dev, nullptr, 0, 0, stream);
+}
+
+extern "C" int vct_adam_step_pk(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
+                                const float* hyper_dev, const vct_adam_pack_seg* segs_dev, int32_t nseg, int64_t base, void* stream) {
+  static_assert(sizeof(vct_adam_pack_seg) == sizeof(AdamPackSeg), "descriptor layout");
+  if (nseg < 0 || (nseg > 0 && (segs_dev == nullptr || shadow_bf16 == nullptr || (base & 3)))) return VCT_E_ARG;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return VCT_E_ARG;
   if (n < 0 || (n & 3)) return VCT_E_SHAPE;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VCT_E_ALIGN;
@@ -134,7 +170,8 @@ extern "C" int vct_adam_step(float* param, const float* grad, float* exp_avg, fl
   const int64_t want = ((n >> 2) + 255) / 256;
   const int blocks = (int)(want > 8192 ? 8192 : want);
   vct::launch(adam_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end, hyper_dev);
+                     beta1, beta2, eps, weight_decay, step_dev, shadow_skip_begin, shadow_skip_end, hyper_dev,
+                     reinterpret_cast<const AdamPackSeg*>(segs_dev), (int)nseg, base);
   VCT_CHECK_LAUNCH();
   if (bump_step) {
     vct::launch(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);

@@ -88,6 +88,7 @@ class ParamSet:
         # STREAM-ORDER packed copies of whole stacks (key -> [tensor, chunks per layer, [[start, end, blocks, dirty] per layer]]): the operand of the
         # sample-stationary layer kernels (ops.layer_ss_fwd), kept in step with the shadow exactly like the eager transposed copies
         self.packed = {}
+        self._adam_pack = {}
         # MFMA-fragment-major copies of single decoder weights (name -> [tensor, version]): operands of the batched block decode
         # (ops.decode_bblock), refreshed on demand like the lazy transposed copies (decode entry points)
         self.fragpacked = {}
@@ -211,15 +212,81 @@ class ParamSet:
                 ops.pack_frag(self.c[name], ent[0])
                 ent[1] = self.version
 
-    def refresh_transposed(self, a: int, b: int, skip=()):
+    def adam_pack_table(self, a: int, b: int):
+        """(device table of vct_adam_pack_seg, entries, [parts]) for the packed parts whose weights lie inside flat elements [a, b):
+        the optimizer's pass over [a, b) writes their stream-order copies itself (ops.adam_step(pack=...)).  Parts with transposed
+        blocks (the backward's stream) and matrices whose blocks are not whole 512-row blocks / 512-column slices stay with vct_ss_pack.
+        The table is built once per (a, b) and set of streams (pointers are static)."""
+        key = (a, b, tuple(sorted(self.packed)))
+        hit = self._adam_pack.get(key)
+        if hit is not None:
+            return hit
+        import bisect
+        starts = sorted((off, n) for n, off in self.offsets.items())
+        segs, parts = {}, []
+        c0 = self.cflat.data_ptr()
+        for ent in self.packed.values():
+            for sub in ent[2]:
+                if not (a <= sub[0] and sub[1] <= b):
+                    continue
+                ok, mine = True, {}
+                for blk in sub[2]:
+                    w, nch, dc = blk[:3]
+                    if len(blk) > 3 and blk[3]:
+                        ok = False
+                        break
+                    eo = (w.data_ptr() - c0) // 2
+                    i = bisect.bisect_right(starts, (eo, chr(0x10ffff))) - 1
+                    mo, name = starts[i]
+                    shape = self.params[name].shape
+                    if len(shape) != 2 or w.stride(0) != shape[1]:
+                        ok = False
+                        break
+                    N, K = shape
+                    r0, cc0 = (eo - mo) // K, (eo - mo) % K
+                    if cc0 == 0 and nch * 64 == K and r0 % 512 == 0 and r0 // 512 < 4:
+                        mode, idx = 0, r0 // 512
+                    elif r0 == 0 and N == 512 and nch == 8 and cc0 % 512 == 0 and cc0 // 512 < 4:
+                        mode, idx = 1, cc0 // 512
+                    else:
+                        ok = False
+                        break
+                    sg = mine.setdefault(name, [mo, mo + N * K, K, mode, [-1, -1, -1, -1], ent[0].data_ptr()])
+                    if sg[3] != mode:
+                        ok = False
+                        break
+                    sg[4][idx] = dc
+                if ok and mine:
+                    segs.update(mine)
+                    parts.append(sub)
+        rows = sorted(segs.values())
+        if rows:
+            arr = (ops.L.AdamPackSeg * len(rows))()
+            for i, (bg, en, K, mode, ch, ptr) in enumerate(rows):
+                arr[i].begin, arr[i].end, arr[i].K, arr[i].mode, arr[i].stream = bg, en, K, mode, ptr
+                for j in range(4):
+                    arr[i].chunk0[j] = ch[j]
+            raw = bytes(arr)
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        else:
+            table = None
+        hit = self._adam_pack[key] = (table, len(rows), parts)
+        return hit
+
+    def refresh_transposed(self, a: int, b: int, skip=(), packed_done=()):
         """Shadow elements [a, b) were just rewritten: eager transposed copies inside follow (except `skip`: already written by
-        the optimizer's fused pass); lazy ones are picked up by want_transposed through `version`."""
+        the optimizer's fused pass); lazy ones are picked up by want_transposed through `version`.  packed_done: parts of packed
+        streams the optimizer's pass wrote itself (adam_pack_table)."""
         for name, ent in self.transposed.items():
             if ent[3] and name not in skip and a <= ent[1] and ent[2] <= b:
                 ops.transpose(self.c[name], ent[0])
+        done = set(id(x) for x in packed_done)
         for ent in self.packed.values():
             todo = []
             for sub in ent[2]:
+                if id(sub) in done:
+                    sub[3] = False
+                    continue
                 if sub[1] > a and sub[0] < b:                 # the rewritten range touches this part
                     if a <= sub[0] and sub[1] <= b:
                         todo += sub[2]

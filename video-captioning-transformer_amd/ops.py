@@ -493,11 +493,18 @@ def advance_seed(seed):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step_dev, skip=(0, 0), bump=True,
-              hyper=None):
+              hyper=None, pack=None):
     """Fused Adam/AdamW over flat fp32 buffers (+ bf16 shadow refresh).  step_dev: int32[1] device counter.
     `param` may be a slice of the flat buffer (range-by-range stepping): pass the same slice of every buffer,
     `skip` relative to the slice start, bump=False, and finish with adam_bump(step_dev).  hyper: device fp32 [5]
     (lr, beta1, beta2, eps, weight_decay) read by the kernel instead of the scalars (graph / launch-list replays)."""
+    if pack is not None:      # (device table of vct_adam_pack_seg, entries, flat index of param[0]): packed weight copies written in the same pass
+        table, nseg, base = pack
+        L.check(L.load().vct_adam_step_pk(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
+                                          param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                          step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.ptr(hyper),
+                                          table.data_ptr(), int(nseg), int(base), L.stream_ptr()), "vct_adam_step_pk")
+        return
     L.check(L.load().vct_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
                                    param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.ptr(hyper), L.stream_ptr()),

@@ -234,6 +234,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_range(0, self.end)
         self.finish_ranges()
 
+    # A/B switch: the optimizer's pass writes the stream-order packed weight copies itself (instead of vct_ss_pack launches behind it)
+    pack_in_adam = os.environ.get("VCT_ADAM_PACK", "1") != "0"
+
     @torch.no_grad()
     def step_range(self, a: int, b: int):
         """Adam on flat elements [a, b) only, without advancing the step counter (range-by-range stepping as
@@ -250,13 +253,17 @@ class FusedAdam(torch.optim.Optimizer):
         if os.environ.get("VCT_ADAM2D", "1") == "0":      # A/B switch: transposed shadow by a transpose launch behind the flat pass
             fused = []
 
+        # stream-order packed weight copies (the sample-stationary stack kernels' operand) inside the range: written by the same pass
+        table, nseg, pk_parts = ps.adam_pack_table(a, b) if (bf and self.pack_in_adam and ps.packed) else (None, 0, [])
+
         def flat_range(lo, hi):
             if hi <= lo:
                 return
             shadow = ps.cflat[lo:hi] if bf else None
             s0, s1 = max(self.skip[0], lo) - lo, min(self.skip[1], hi) - lo
             ops.adam_step(ps.flat[lo:hi], ps.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], shadow, lr, b1, b2, eps, wd,
-                          self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper)
+                          self.step_dev, (s0, s1) if s1 > s0 else (0, 0), bump=False, hyper=self.hyper,
+                          pack=(table, nseg, lo) if nseg else None)
         cur = a
         for name, t, x, y in fused:
             flat_range(cur, x)
@@ -267,7 +274,7 @@ class FusedAdam(torch.optim.Optimizer):
             cur = y
         flat_range(cur, b)
         if bf:
-            ps.refresh_transposed(a, b, skip=[f[0] for f in fused])   # other eager copies follow the shadow this pass rewrote
+            ps.refresh_transposed(a, b, skip=[f[0] for f in fused], packed_done=pk_parts)   # other eager copies follow the shadow this pass rewrote
 
     @torch.no_grad()
     def finish_ranges(self):
