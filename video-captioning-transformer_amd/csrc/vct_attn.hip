@@ -16,17 +16,22 @@
 
 namespace vct {
 
+// One workgroup per (batch, head): ONE wave for the short sequences of the caption configs (two 16-row tiles at most: a second wave
+// idles on a single key tile and the two contend for LDS -- measured slower in round 1), blockDim.x / 64 waves for three or four
+// tiles (configs[3]: 40 x 40 x 128 -- the 70 KB of staged operands leave two workgroups per CU, i.e. two WAVES per CU with one wave
+// each): the waves stage together and take the query tiles (forward, backward phase A) / key tiles (phase B) in turn.
 template <typename T, int DT>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  attn_fwd_wave<T, DT>(p, blockIdx.x / p.H, blockIdx.x % p.H, blockIdx.x, smem, threadIdx.x, (T*)nullptr, 0);
+  attn_fwd_wave<T, DT>(p, blockIdx.x / p.H, blockIdx.x % p.H, blockIdx.x, smem, threadIdx.x, (T*)nullptr, 0, (int)(blockDim.x >> 6));
 }
 
 template <typename T, int DT>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
   using C = AttnCfg<T, DT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int LQT = (p.Lq + 15) / 16, LKT = (p.Lk + 15) / 16;
   const int RQ = ((LQT + 1) / 2) * 32, RK = ((LKT + 1) / 2) * 32;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
   T* dvg = reinterpret_cast<T*>(p.dv) + (long)b * p.Lk * p.ld_dv + (long)h * p.hd;
   {
     const StageJob<T> jobs[4] = {{Qs, qg, p.ldq, p.Lq, RQ}, {dOs, dog, p.ld_do, p.Lq, RQ}, {Ks, kg, p.ldk, p.Lk, RK}, {Vs, vg, p.ldv, p.Lk, RK}};
-    stage_multi<T, DT, 4>(jobs, p.hd, lane);
+    stage_multi<T, DT, 4>(jobs, p.hd, (int)threadIdx.x, nwv * 64);
   }
   __syncthreads();
   const unsigned long long kp_row = load_padmask(p, b, lane);
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
   const int hd4 = (p.hd + 3) / 4;
 
   // ---------------- phase A: per query tile, transposed form -> stats + dQ ----------------
-  for (int qt = 0; qt < LQT; qt++) {
+  for (int qt = wv; qt < LQT; qt += nwv) {
     f32x4 st[4], dpt[4];
     scores_T<T, DT>(st, Ks, Qs, qt, LKT, hd4, scale, p, kp_row, lane);
     float m = -INFINITY;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnP p) {
   __syncthreads();  // stats visible
 
   // ---------------- phase B: per key tile, un-transposed form -> dV, dK ----------------
-  for (int t = 0; t < LKT; t++) {
+  for (int t = wv; t < LKT; t += nwv) {
     f32x4 av[DT], ak[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) { av[dt] = f32x4{0, 0, 0, 0}; ak[dt] = f32x4{0, 0, 0, 0}; }
@@ -231,8 +236,15 @@ template <typename T, int DT> static int attn_launch(const AttnP& p, bool bwd, h
     attr[bwd] = (int)lds;
   }
   const dim3 grid(p.B * p.H);
-  if (bwd) vct::launch((attn_bwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
-  else vct::launch((attn_fwd_kernel<T, DT>), grid, dim3(64), lds, st, p);
+  const int LQT = (p.Lq + 15) / 16, LKT = (p.Lk + 15) / 16;
+  const int tiles = bwd ? (LQT > LKT ? LQT : LKT) : LQT;
+  static const char* wenv = getenv("VCT_ATTN_WAVES");          // A/B: 0 = by shape, n = force
+  // measured (round 4, same box): configs[3] (3 x 3 tiles, head_dim 128) 18.94 -> 17.36 ms per step with 3 waves; the shipped shape
+  // (2 tiles, head_dim 96) 3.57 -> 3.52 ms with 2; cfg-B (2 tiles, head_dim 64: five to six workgroups fit a CU) stays at one wave
+  int nwv = tiles >= 3 ? (tiles < 4 ? tiles : 4) : (tiles == 2 && p.hd > 64 ? 2 : 1);
+  if (wenv != nullptr && atoi(wenv) > 0) nwv = atoi(wenv) < 4 ? atoi(wenv) : 4;
+  if (bwd) vct::launch((attn_bwd_kernel<T, DT>), grid, dim3(64 * nwv), lds, st, p);
+  else vct::launch((attn_fwd_kernel<T, DT>), grid, dim3(64 * nwv), lds, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }

@@ -48,25 +48,25 @@ struct alignas(16) AV16 { uint32_t w[4]; };
 template <typename T> struct StageJob { T* lds; const T* g; long ld; int L; int rows_alloc; };
 
 template <typename T, int DT>
-__device__ __forceinline__ void stage_load4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane) {
+__device__ __forceinline__ void stage_load4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane, int nt = 64) {
   using C = AttnCfg<T, DT>;
   constexpr int VPR = C::HDK / C::VEC;
   const int total = j.rows_alloc * VPR;
 #pragma unroll
   for (int u = 0; u < 4; u++) {
-    const int idx = min(base + u * 64 + lane, total - 1);
+    const int idx = min(base + u * nt + lane, total - 1);
     const int r = min(idx / VPR, j.L - 1), c = min((idx % VPR) * C::VEC, hd - C::VEC);
     val[u] = *reinterpret_cast<const AV16*>(j.g + (long)r * j.ld + c);
   }
 }
 template <typename T, int DT>
-__device__ __forceinline__ void stage_commit4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane) {
+__device__ __forceinline__ void stage_commit4(AV16 (&val)[4], const StageJob<T>& j, int base, int hd, int lane, int nt = 64) {
   using C = AttnCfg<T, DT>;
   constexpr int VPR = C::HDK / C::VEC;
   const int total = j.rows_alloc * VPR;
 #pragma unroll
   for (int u = 0; u < 4; u++) {
-    const int idx = base + u * 64 + lane;
+    const int idx = base + u * nt + lane;
     if (idx < total) {
       const int r = idx / VPR, c = (idx % VPR) * C::VEC;
       if (r >= j.L || c >= hd) val[u].w[0] = val[u].w[1] = val[u].w[2] = val[u].w[3] = 0u;
@@ -74,21 +74,23 @@ __device__ __forceinline__ void stage_commit4(AV16 (&val)[4], const StageJob<T>&
     }
   }
 }
+// lane / nt: the staging thread's index and the number of threads that stage together (one wave: lane, 64; a whole multi-wave
+// workgroup: threadIdx.x, blockDim.x -- then a 64 x 128 slice is one round trip instead of four)
 template <typename T, int DT, int NJ>
-__device__ __forceinline__ void stage_multi(const StageJob<T> (&jobs)[NJ], int hd, int lane) {
+__device__ __forceinline__ void stage_multi(const StageJob<T> (&jobs)[NJ], int hd, int lane, int nt = 64) {
   using C = AttnCfg<T, DT>;
   constexpr int VPR = C::HDK / C::VEC;
   AV16 val[NJ][4];
 #pragma unroll
-  for (int j = 0; j < NJ; j++) stage_load4<T, DT>(val[j], jobs[j], 0, hd, lane);
+  for (int j = 0; j < NJ; j++) stage_load4<T, DT>(val[j], jobs[j], 0, hd, lane, nt);
 #pragma unroll
-  for (int j = 0; j < NJ; j++) stage_commit4<T, DT>(val[j], jobs[j], 0, hd, lane);
+  for (int j = 0; j < NJ; j++) stage_commit4<T, DT>(val[j], jobs[j], 0, hd, lane, nt);
 #pragma unroll
-  for (int j = 0; j < NJ; j++) {       // slices with more than 256 vectors (long sequences / wide heads)
+  for (int j = 0; j < NJ; j++) {       // slices with more than 4 vectors per staging thread (long sequences / wide heads)
     const int total = jobs[j].rows_alloc * VPR;
-    for (int base = 256; base < total; base += 256) {
-      stage_load4<T, DT>(val[0], jobs[j], base, hd, lane);
-      stage_commit4<T, DT>(val[0], jobs[j], base, hd, lane);
+    for (int base = 4 * nt; base < total; base += 4 * nt) {
+      stage_load4<T, DT>(val[0], jobs[j], base, hd, lane, nt);
+      stage_commit4<T, DT>(val[0], jobs[j], base, hd, lane, nt);
     }
   }
 }
@@ -190,7 +192,10 @@ __device__ __forceinline__ void scores_T(f32x4 (&st)[4], const T* Ks, const T* Q
 // computed from zero-padded Q: finite values the consumer ignores).  bh = b*H + h indexes the dropout stream.
 template <typename T, int DT>
 __device__ __forceinline__ void attn_fwd_wave(const AttnP& p, const int b, const int h, const int bh, unsigned char* smem,
-                                              const int lane, T* o_lds, const long o_lds_stride) {
+                                              const int lane_in, T* o_lds, const long o_lds_stride, const int nwv = 1) {
+  // nwv > 1: `smem` is shared by the nwv waves of the workgroup (lane_in = threadIdx.x): they stage together and take the query
+  // tiles in turn
+  const int lane = lane_in & 63, wv = lane_in >> 6;
   using C = AttnCfg<T, DT>;
   const int i = lane & 15, g = lane >> 4;
   const int LQT = (p.Lq + 15) / 16, LKT = (p.Lk + 15) / 16;
@@ -204,7 +209,7 @@ __device__ __forceinline__ void attn_fwd_wave(const AttnP& p, const int b, const
   T* og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)h * p.hd;
   {
     const StageJob<T> jobs[3] = {{Qs, qg, p.ldq, p.Lq, RQ}, {Ks, kg, p.ldk, p.Lk, RK}, {Vs, vg, p.ldv, p.Lk, RK}};
-    stage_multi<T, DT, 3>(jobs, p.hd, lane);
+    stage_multi<T, DT, 3>(jobs, p.hd, lane_in, nwv * 64);
   }
   __syncthreads();
   const unsigned long long kp_row = load_padmask(p, b, lane);
@@ -212,7 +217,7 @@ __device__ __forceinline__ void attn_fwd_wave(const AttnP& p, const int b, const
   const float scale = 1.0f / sqrtf((float)p.hd);
   const int hd4 = (p.hd + 3) / 4;
 
-  for (int qt = 0; qt < LQT; qt++) {
+  for (int qt = wv; qt < LQT; qt += nwv) {
     f32x4 st[4];
     scores_T<T, DT>(st, Ks, Qs, qt, LKT, hd4, scale, p, kp_row, lane);
     float m = -INFINITY;
