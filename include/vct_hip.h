@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 10
+#define VCT_ABI_VERSION 12
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -54,6 +54,27 @@ int vct_build_info(char* buf, int buflen);
  * inside nn.Transformer{En,De}coderLayer -- torch nn/modules/transformer.py:951-982,1143-1199 and
  * nn/functional.py:5785,6637) and its autograd backward (dX = dY*W: ta=0,tb=0; dW = dY^T*X: ta=1,tb=0).
  * --------------------------------------------------------------------------------------------- */
+/* Optional OPTIMIZER epilogue of the weight-gradient form (dtype bf16, out fp32, ta=1, tb=0; vct_gemm and vct_gemm_grouped): the
+ * gradient element g the product would store to C[r, c] is consumed in the epilogue registers by torch.optim.Adam's update of the
+ * parameter element it belongs to,
+ *     m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p = p (1 - lr wd) - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * (exactly vct_adam_step's arithmetic; t = *step + 1, hyper = {lr, beta1, beta2, eps, weight_decay} in DEVICE memory), and the
+ * refreshed bf16 shadow / stream-order packed copy of the weight are written from the same registers.
+ * replaces: `optimizer.step()` of the reference (train.py:24-26,126: torch.optim.Adam over the weight) for THIS matrix, and the
+ * 4 B / parameter gradient store + re-load between `loss.backward()` (train.py:125) and it -- the optimizer's HBM pass over the
+ * matrix runs inside the MFMA-bound product that produced its gradient instead of as a serial tail of the step.
+ *   param / exp_avg / exp_avg_sq: fp32 [M, ldc] -- element (r, c) at r * ldc + c, the layout of C (views of flat buffers at C's offset).
+ *   shadow: bf16 [M, ld_shadow] or NULL.  pk_*: the matrix's stream-order packed copy as in vct_adam_pack_seg (K = row length of the
+ *   WHOLE weight, pk_row0 = row of the whole weight that C's row 0 is, pk_stream NULL = none).
+ *   store_grad != 0: C is written as well (tests, gradient hooks); 0: C is left untouched.
+ * Single GPU only: a data-parallel exchange has to average g first (trainer.ShardedExchange keeps the separate pass). */
+typedef struct vct_gemm_adam {
+  float* param; float* exp_avg; float* exp_avg_sq;
+  void* shadow; int64_t ld_shadow;
+  void* pk_stream; int32_t pk_K, pk_mode; int32_t pk_chunk0[4]; int32_t pk_row0; int32_t store_grad;
+  const float* hyper; const int32_t* step;
+} vct_gemm_adam;
+
 typedef struct vct_gemm_desc {
   int32_t dtype;      /* VCT_F32 | VCT_BF16 : element type of A and B */
   int32_t out_dtype;  /* element type of C, preact, addend */
@@ -75,6 +96,7 @@ typedef struct vct_gemm_desc {
                                                the general kernel, 100 = force / 99 = forbid the persistent-tile layer kernel */
   int32_t n_tile_counters;                  /* ints available at tile_counters */
   int32_t* tile_counters;                   /* optional, see below */
+  const vct_gemm_adam* adam;                /* optional (NULL = none): optimizer epilogue of the dW form, see vct_gemm_adam */
 } vct_gemm_desc;
 /* tile_counters: device ints that are ZERO on entry (they are zero again when the GEMM has finished, so one
  * zero-filled allocation serves every later call on the same stream).  With them a split-K GEMM reduces inside
@@ -315,6 +337,40 @@ int vct_ln_ws_rows(int M);
 int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-panel Linear backward (bf16, csrc/vct_rowpanel.hip): the input-gradient product of an nn.Linear of the layers' dX chain
+ *     dX[M, N] = epilogue(dY[M, K] W),   W = the Linear's weight [out = K, in = N],  N a multiple of 512
+ * with a workgroup per 32-row panel that keeps its dY rows in LDS and reads W as the TRANSPOSED stream-order packed blocks of
+ * vct_ss_pack (block j = rows [512 j, 512 j + 512) of W^T: segment {w = W + 512 j, ldw = N, nchunks = K / 64, transposed = 1},
+ * blocks back to back).  Complete rows per workgroup make the row-wise op behind the product an epilogue:
+ *   epi 0: out = acc (+ addend)                                       -- out_proj / q / k|v projections' input gradients
+ *   epi 1: out = acc * act'(hpre) * dropout-mask(site, row * N + col) -- linear2's input gradient = gradient of the pre-activation
+ *   epi 2: LayerNorm backward of the norm whose OUTPUT the Linear read (post-norm layers): gy = acc + addend, then exactly
+ *          vct_add_ln_bwd(dy = gy, x = norm.xs, res = norm.res, ...): ds, dxo (NULL = not stored), and one (dgamma | dbeta)
+ *          partial row pair per panel in norm.ws [ceil(M / 32)][2][512] fp32 (vct_ln_param_finalize_batched sums them: rows = panels)
+ * replaces: the autograd nodes of F.linear / F.gelu / nn.Dropout / nn.LayerNorm inside nn.TransformerEncoderLayer /
+ * nn.TransformerDecoderLayer (torch nn/modules/transformer.py:951-982,1143-1199; built at MMEncoder.py:236-238, CapDecoder.py:18-20)
+ * run by `loss.backward()` (train.py:125) -- i.e. one vct_gemm (ta = 0, tb = 0) + one vct_add_ln_bwd launch of the unfused schedule.
+ * vct_rp_linear_supported: bf16, N % 512 == 0 (epi 0 / 2: N == 512), K % 128 == 0, LDS <= 160 KiB.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct vct_rp_norm_bwd {
+  const float* gamma; const float* mean; const float* rstd; float* ws;
+  const void* xs; const void* res; void* ds; void* dxo;
+  uint32_t site, reserved;
+} vct_rp_norm_bwd;
+typedef struct vct_rp_linear_desc {
+  int32_t dtype, M, N, K, epi, act;
+  const void* A; int64_t lda;
+  const void* wpk;
+  void* out; int64_t ldo;
+  const void* addend; int64_t ld_addend;
+  const void* hpre; int64_t ld_hpre;
+  const uint32_t* seed; uint32_t site; float p_drop;
+  vct_rp_norm_bwd norm;
+} vct_rp_linear_desc;
+int vct_rp_linear_supported(int dtype, int N, int K, int epi);
+int vct_rp_linear(const vct_rp_linear_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Encoder front end after the `unify` GEMM: z[b,0] = mean_t u[b,t] (all T rows, pads included),
  * z[b,t+1] = u[b,t] + pe_rows[t+1]  (pe_rows fp32 [T+1,d], row 0 = 0).
  * replaces: GlobalAggregation('avg') + cat + TemporalEncoding add (MMEncoder.py:196-197,248-250,
@@ -395,6 +451,17 @@ int vct_adam_step_pk(float* param, const float* grad, float* exp_avg, float* exp
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int32_t* step_dev, int64_t shadow_skip_begin, int64_t shadow_skip_end, int32_t bump_step,
                      const float* hyper_dev, const vct_adam_pack_seg* segs_dev, int32_t nseg, int64_t base, void* stream);
+/* The same step over a LIST of flat ranges in ONE launch -- what is left for a separate pass when the weight matrices are stepped by
+ * the optimizer epilogue of their own weight-gradient GEMMs (vct_gemm_adam): biases, LayerNorm parameters, the token-embedding table.
+ * param / grad / exp_avg / exp_avg_sq / shadow_bf16: the WHOLE flat buffers; ranges_dev: device array sorted by begin, [begin, end)
+ * flat elements (multiples of 4), blk0 = number of 4096-element workgroups of all earlier ranges, shadow != 0: write the bf16 shadow
+ * (and the packed copies of segs_dev, flat indices as in vct_adam_step_pk with base 0); total_blocks = workgroups of all ranges.
+ * No step-counter bump.  replaces torch.optim.Adam.step (train.py:24-26,126) for those parameters. */
+typedef struct vct_adam_range { int64_t begin, end; int32_t blk0, shadow; } vct_adam_range;
+int vct_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                         const vct_adam_range* ranges_dev, int32_t nranges, int32_t total_blocks, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int32_t* step_dev, const float* hyper_dev,
+                         const vct_adam_pack_seg* segs_dev, int32_t nseg, void* stream);
 int vct_adam_step_2d(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                      void* shadow_t_bf16, int32_t rows, int32_t cols, int64_t ld_t, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t* step_dev, const float* hyper_dev, void* stream);

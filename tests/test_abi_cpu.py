@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 12
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -88,6 +88,11 @@ int main(void) {
          offsetof(vct_decode_bblock_desc, ld_y));
   printf("%zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_bwd_desc), offsetof(vct_layer_ss_bwd_desc, wpk), offsetof(vct_layer_ss_bwd_desc, n3),
          offsetof(vct_layer_ss_bwd_desc, key_pad), offsetof(vct_layer_ss_bwd_desc, site_n3));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vct_gemm_adam), offsetof(vct_gemm_adam, shadow), offsetof(vct_gemm_adam, pk_stream),
+         offsetof(vct_gemm_adam, pk_chunk0), offsetof(vct_gemm_adam, store_grad), offsetof(vct_gemm_adam, step), offsetof(vct_gemm_desc, adam),
+         sizeof(vct_adam_range));
+  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vct_rp_linear_desc), offsetof(vct_rp_linear_desc, wpk), offsetof(vct_rp_linear_desc, hpre),
+         offsetof(vct_rp_linear_desc, p_drop), offsetof(vct_rp_linear_desc, norm), sizeof(vct_rp_norm_bwd));
   return 0;
 }''')
     exe = tmp_path / "sz"
@@ -100,7 +105,11 @@ int main(void) {
                    ctypes.sizeof(_lib.DecodeBBlockDesc), _lib.DecodeBBlockDesc.ids.offset, _lib.DecodeBBlockDesc.w_a.offset,
                    _lib.DecodeBBlockDesc.ld_y.offset,
                    ctypes.sizeof(_lib.LayerSsBwdDesc), _lib.LayerSsBwdDesc.wpk.offset, _lib.LayerSsBwdDesc.n3.offset,
-                   _lib.LayerSsBwdDesc.key_pad.offset, _lib.LayerSsBwdDesc.site_n3.offset]
+                   _lib.LayerSsBwdDesc.key_pad.offset, _lib.LayerSsBwdDesc.site_n3.offset,
+                   ctypes.sizeof(_lib.GemmAdam), _lib.GemmAdam.shadow.offset, _lib.GemmAdam.pk_stream.offset, _lib.GemmAdam.pk_chunk0.offset,
+                   _lib.GemmAdam.store_grad.offset, _lib.GemmAdam.step.offset, G.adam.offset, ctypes.sizeof(_lib.AdamRange),
+                   ctypes.sizeof(_lib.RpLinearDesc), _lib.RpLinearDesc.wpk.offset, _lib.RpLinearDesc.hpre.offset, _lib.RpLinearDesc.p_drop.offset,
+                   _lib.RpLinearDesc.norm.offset, ctypes.sizeof(_lib.RpNormBwd)]
 
 
 def test_layer_ss_entry_points_validate_arguments(lib_path):

@@ -278,7 +278,7 @@ def test_shipped_width_fp32_batch1_decode_takes_the_batched_step():
             _compare_until_margin(ys, ref_ys, margins, 0.15)
 
 
-def test_first_overlapped_step_leaves_exact_adam_moments():
+def test_first_overlapped_step_leaves_exact_adam_moments(monkeypatch):
     """From zero moments the first step must leave m = (1 - b1) g and v = ((1 - b2) g) g of ITS OWN gradient, bitwise, for every
     parameter of the caption path -- at the bench batch, where Adam on the decoder / vocabulary part runs beside the encoder
     backward on the second stream.  Anything else means Adam read a gradient that was still being written, somebody else wrote the
@@ -292,11 +292,14 @@ def test_first_overlapped_step_leaves_exact_adam_moments():
     feats, mask, idt = _to_dev(f, mk, ids)
     c1 = (torch.tensor(1.0) - torch.tensor(0.9)).to(DEV)
     c2 = (torch.tensor(1.0) - torch.tensor(0.999)).to(DEV)
-    for drop in (0.3, 0.0, 0.0):
+    monkeypatch.setattr(FusedAdam, "keep_grads", True)      # the optimizer epilogue of the weight-gradient GEMMs also stores the gradient it consumed
+    for drop, fuse in ((0.3, True), (0.0, True), (0.0, False)):
         mm = build_model(dict(mc, dropout=drop), V, DEV, torch.bfloat16, p)
         mm.train(); mm._seed.fill_(99)
         opt = FusedAdam(mm, lr=1e-4)
-        CaptionTrainer(mm, opt, launch_list=True).step(feats, mask, idt)
+        tr = CaptionTrainer(mm, opt, launch_list=True)
+        tr.fuse_adam = fuse
+        tr.step(feats, mask, idt)
         torch.cuda.synchronize()
         e = mm.caption_param_end
         g = mm.flat_grads[:e]

@@ -221,6 +221,52 @@ def test_adam_after_the_joined_backward_is_the_same_step(executor, monkeypatch):
     assert torch.equal(l0, l1) and torch.equal(p0, p1)
 
 
+@pytest.mark.parametrize("executor", ["eager", "list"])
+def test_optimizer_inside_the_weight_gradient_gemms_is_the_separate_pass(executor, monkeypatch):
+    """CaptionTrainer.fuse_adam (default on one GPU): every weight matrix is stepped in the epilogue of its own weight-gradient GEMM,
+    the rest by one multi-range launch.  Same kernels otherwise, same arithmetic: parameters, both moments and the bf16 shadow
+    must be BITWISE what the separate optimizer pass leaves (the vocabulary dX in its NN form on both sides: the epilogue
+    maintains no W_g^T)."""
+    from vct_amd.engine import DecoderEngine
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    monkeypatch.setattr(DecoderEngine, "gen_dx_nt", False)
+    res = {}
+    for fuse in (True, False):
+        m = _model()
+        m._seed.fill_(1234)
+        opt = FusedAdam(m, lr=1e-3, weight_decay=0.01)
+        tr = CaptionTrainer(m, opt, launch_list=executor == "list")
+        assert tr.fuse_adam is True
+        tr.fuse_adam = fuse
+        losses = torch.cat([tr.step(*_batch(100 + k)).clone() for k in range(4)])
+        torch.cuda.synchronize()
+        e = m.caption_param_end
+        res[fuse] = (losses, m.flat_params.clone(), opt.exp_avg[:e].clone(), opt.exp_avg_sq[:e].clone(), m._ps.cflat[:e].clone(),
+                     int(opt.step_dev))
+        assert m._ps.dw_adam is None                         # the hook is installed only while the trainer enqueues a step
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    assert res[True][5] == 4
+
+
+def test_plain_backward_beside_a_fusing_trainer_still_produces_gradients():
+    """The reference call sequence (train.py:123-125) on a model whose trainer fuses the optimizer into the weight-gradient GEMMs:
+    loss.backward() outside the trainer leaves the parameters alone and fills .grad."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    m = _model(dropout=0.0)
+    tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), launch_list=True)
+    tr.step(*_batch(100)); tr.step(*_batch(101))
+    torch.cuda.synchronize()
+    before = m.flat_params.clone()
+    f, k, i = _batch(102)
+    m.zero_grad(set_to_none=False)
+    m([f], [k], i).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, before)
+    g = m._ps.g["cap_decoder.generator.weight"]
+    assert float(g.abs().max()) > 0 and bool(torch.isfinite(g).all())
+
+
 def test_adopted_input_buffers_skip_the_staging_copies_and_give_the_same_step():
     """CaptionTrainer.adopt_inputs: a producer that writes its batches into the executor's own static buffers; same losses and
     parameters as passing fresh tensors (which step() copies into those buffers)."""
@@ -252,6 +298,7 @@ def test_vocabulary_dx_through_the_maintained_transposed_shadow(monkeypatch):
         m = _model()
         m._seed.fill_(1234)
         tr = CaptionTrainer(m, FusedAdam(m, lr=1e-3), launch_list=executor == "list")
+        tr.fuse_adam = False         # (the optimizer epilogue of the weight-gradient GEMMs keeps no W_g^T: this is the separate-pass configuration)
         losses = [tr.step(*_batch(100 + k)).clone() for k in range(4)]
         torch.cuda.synchronize()
         ps = m._ps

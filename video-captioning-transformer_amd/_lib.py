@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 12
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -19,13 +19,24 @@ _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported
 vp, i32, i64, u32, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
 
 
+class GemmAdam(C.Structure):
+    """include/vct_hip.h, vct_gemm_adam: optimizer epilogue of a weight-gradient GEMM."""
+    _fields_ = [("param", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("shadow", vp), ("ld_shadow", i64),
+                ("pk_stream", vp), ("pk_K", i32), ("pk_mode", i32), ("pk_chunk0", i32 * 4), ("pk_row0", i32), ("store_grad", i32),
+                ("hyper", vp), ("step", vp)]
+
+
+class AdamRange(C.Structure):
+    _fields_ = [("begin", i64), ("end", i64), ("blk0", i32), ("shadow", i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("dtype", i32), ("out_dtype", i32), ("ta", i32), ("tb", i32), ("M", i32), ("N", i32), ("K", i32),
                 ("act", i32), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
                 ("bias", vp), ("preact", vp), ("ld_preact", i64), ("addend", vp), ("ld_addend", i64),
                 ("dact_src", vp), ("ld_dact", i64), ("seed", vp), ("site", u32), ("p_drop", f32),
                 ("bias_grad", vp), ("workspace", vp), ("workspace_bytes", i64), ("split_k", i32), ("reserved", i32),
-                ("n_tile_counters", i32), ("tile_counters", vp)]
+                ("n_tile_counters", i32), ("tile_counters", vp), ("adam", C.POINTER(GemmAdam))]
 
 
 class AttnDesc(C.Structure):
@@ -77,6 +88,17 @@ class AdamPackSeg(C.Structure):
 
 class SsBwdNorm(C.Structure):
     _fields_ = [("gamma", vp), ("mean", vp), ("rstd", vp), ("ws", vp)]
+
+
+class RpNormBwd(C.Structure):
+    _fields_ = [("gamma", vp), ("mean", vp), ("rstd", vp), ("ws", vp), ("xs", vp), ("res", vp), ("ds", vp), ("dxo", vp),
+                ("site", u32), ("reserved", u32)]
+
+
+class RpLinearDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("epi", i32), ("act", i32), ("A", vp), ("lda", i64), ("wpk", vp),
+                ("out", vp), ("ldo", i64), ("addend", vp), ("ld_addend", i64), ("hpre", vp), ("ld_hpre", i64),
+                ("seed", vp), ("site", u32), ("p_drop", f32), ("norm", RpNormBwd)]
 
 
 class LayerSsBwdDesc(C.Structure):
@@ -138,6 +160,8 @@ _SIGS = {
     "vct_layer_ss_stream_chunks": (i64, [C.c_int, C.c_int]),
     "vct_ss_pack": (C.c_int, [C.POINTER(SsPackSeg), C.c_int, vp, vp]),
     "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), C.c_int, vp]),
+    "vct_rp_linear_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vct_rp_linear": (C.c_int, [C.POINTER(RpLinearDesc), vp]),
     "vct_layer_ss_bwd_stream_chunks": (i64, [C.c_int]),
     "vct_layer_ss_bwd": (C.c_int, [C.POINTER(LayerSsBwdDesc), C.c_int, vp]),
     "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -168,6 +192,7 @@ _SIGS = {
     "vct_gather_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vct_adam_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp]),
     "vct_adam_step_pk": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i64, i64, i32, vp, vp, C.c_int, i64, vp]),
+    "vct_adam_step_ranges": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
     "vct_adam_step_2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
     "vct_cmdlist_create": (C.c_int, [C.POINTER(vp)]),
     "vct_cmdlist_destroy": (C.c_int, [vp]),
@@ -215,10 +240,16 @@ def load():
     if _lib is not None:
         return _lib
     if _AB_LIB:
+        # developer A/B library (tools/ab_build.sh): no stamp (it is built from an older header on purpose), but the same ABI gate as
+        # the in-tree library -- a .so with another entry-point table must not be driven through this ctypes table
         lib = C.CDLL(_AB_LIB)
         for name, (res, args) in _SIGS.items():
+            if not hasattr(lib, name):
+                raise RuntimeError(f"VCT_LIB_PATH={_AB_LIB}: symbol {name} is missing (built from another include/vct_hip.h)")
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.vct_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"VCT_LIB_PATH={_AB_LIB}: ABI version {lib.vct_abi_version()} != {ABI_VERSION}")
         _lib = lib
         return lib
     _ensure_current()

@@ -228,12 +228,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
 template <typename T, int DT> static int attn_launch(const AttnP& p, bool bwd, hipStream_t st) {
   const size_t lds = attn_lds_bytes<T, DT>(p.Lq, p.Lk, bwd);
   if (lds > 160 * 1024) return VCT_E_SHAPE;
-  static int attr[2] = {0, 0};
-  if (lds > 64 * 1024 && (int)lds > attr[bwd]) {
-    hipError_t e = bwd ? hipFuncSetAttribute((const void*)attn_bwd_kernel<T, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                       : hipFuncSetAttribute((const void*)attn_fwd_kernel<T, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr[bwd] = (int)lds;
+  if (lds > 64 * 1024) {       // opt in to the full 160 KB once per device and direction (the attribute is a maximum, not a request)
+    static vct::DynLdsOptIn optin[2];
+    const void* fn = bwd ? (const void*)attn_bwd_kernel<T, DT> : (const void*)attn_fwd_kernel<T, DT>;
+    if (hipError_t e = optin[bwd].ensure(fn, 160 * 1024); e != hipSuccess) return (int)e;
   }
   const dim3 grid(p.B * p.H);
   const int LQT = (p.Lq + 15) / 16, LKT = (p.Lk + 15) / 16;

@@ -671,13 +671,13 @@ extern "C" int vct_embed_bwd(int dtype, int B, int S, int d, int V, const int64_
   const size_t heavy_lds = (size_t)(8 * 1024 + 8 * 16 + 256 + 3 * 1024 + 32) * sizeof(int) + (size_t)slots * d * sizeof(float);
   const dim3 grid(EMB_HEAVY_WGS + (N + 15) / 16);
   if (dtype == VCT_BF16) {
-    static bool attr = false;
-    if (!attr) { if (hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VCT_E_SHAPE; attr = true; }
+    static vct::DynLdsOptIn optin;
+    if (optin.ensure((const void*)embed_bwd_kernel<bf16_t>, 160 * 1024) != hipSuccess) return VCT_E_SHAPE;
     vct::launch((embed_bwd_kernel<bf16_t>), grid, dim3(1024), heavy_lds, st, N, d, V, flat, (int32_t)pad_id, (const bf16_t*)dx, dtable,
                 first_pos, cnt, seed, site, p_drop);
   } else {
-    static bool attr = false;
-    if (!attr) { if (hipFuncSetAttribute((const void*)embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VCT_E_SHAPE; attr = true; }
+    static vct::DynLdsOptIn optin;
+    if (optin.ensure((const void*)embed_bwd_kernel<float>, 160 * 1024) != hipSuccess) return VCT_E_SHAPE;
     vct::launch((embed_bwd_kernel<float>), grid, dim3(1024), heavy_lds, st, N, d, V, flat, (int32_t)pad_id, (const float*)dx, dtable,
                 first_pos, cnt, seed, site, p_drop);
   }

@@ -13,6 +13,7 @@
 //    through a per-wave fp32 LDS transpose so that every lane stores 16 contiguous bytes, and the deterministic
 //    split-K second pass (splitk_reduce_kernel).
 #include <cstdlib>
+#include <cstring>
 #include "vct_common.h"
 #include "vct_gemm_params.h"
 
@@ -362,7 +363,7 @@ static Plan gemm_plan(const vct_gemm_desc* d, bool have_ws) {
   if (split < 1) split = 1;
   pl.kt_per = (pl.nkt + split - 1) / split;
   pl.split = (pl.nkt + pl.kt_per - 1) / pl.kt_per;
-  if (epilogue && pl.split > 1 && !use_counters(d, pl)) { pl.split = 1; pl.kt_per = pl.nkt; }
+  if ((epilogue || d->adam != nullptr) && pl.split > 1 && !use_counters(d, pl)) { pl.split = 1; pl.kt_per = pl.nkt; }   // (the optimizer epilogue lives in the producing kernel: no two-pass reduce)
   return pl;
 }
 
@@ -419,6 +420,21 @@ static int check_desc(const vct_gemm_desc* d) {
   if (d->dact_src != nullptr && d->act == VCT_ACT_NONE) return VCT_E_ARG;  // dact needs the activation kind
   // bf16 path: the bias gradient is fused into the weight-gradient form only (dW = A^T B, fp32 out)
   if (d->bias_grad != nullptr && d->dtype == VCT_BF16 && !(d->ta == 1 && d->tb == 0 && d->out_dtype == VCT_F32)) return VCT_E_ARG;
+  if (d->adam != nullptr) {
+    // optimizer epilogue: the bf16 weight-gradient form only, nothing else in the epilogue (the gradient is consumed as produced)
+    const vct_gemm_adam* a = d->adam;
+    if (!(d->dtype == VCT_BF16 && d->out_dtype == VCT_F32 && d->ta == 1 && d->tb == 0)) return VCT_E_ARG;
+    if (d->bias != nullptr || d->act != VCT_ACT_NONE || d->preact != nullptr || d->addend != nullptr || d->dact_src != nullptr ||
+        (d->seed != nullptr && d->p_drop > 0.0f))
+      return VCT_E_ARG;
+    if (!a->param || !a->exp_avg || !a->exp_avg_sq || !a->hyper || !a->step) return VCT_E_ARG;
+    if (((uintptr_t)a->param | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq | (uintptr_t)d->C) & 15) return VCT_E_ALIGN;
+    if (d->ldc % 4) return VCT_E_ALIGN;
+    if (a->shadow != nullptr && (((uintptr_t)a->shadow & 7) || (a->ld_shadow % 4))) return VCT_E_ALIGN;
+    if (a->pk_stream != nullptr && (a->shadow == nullptr || ((uintptr_t)a->pk_stream & 15) || a->pk_K < d->N || (a->pk_K % 8) ||
+                                    a->pk_row0 < 0 || (a->pk_mode != 0 && a->pk_mode != 1)))
+      return VCT_E_ARG;
+  }
   return VCT_OK;
 }
 
@@ -438,6 +454,19 @@ static void fill_params(const vct_gemm_desc* d, const Plan& pl, GemmP& p) {
   p.seed = d->seed; p.site = d->site; p.p_drop = d->p_drop;
   p.bias_grad = d->bias_grad;
   p.partial = nullptr; p.bias_partial = nullptr; p.counters = nullptr;
+  memset(&p.adam, 0, sizeof(p.adam));
+  if (d->adam != nullptr) {
+    const vct_gemm_adam* a = d->adam;
+    p.adam.param = a->param; p.adam.m = a->exp_avg; p.adam.v = a->exp_avg_sq;
+    p.adam.shadow = reinterpret_cast<uint16_t*>(a->shadow); p.adam.ld_shadow = (long)a->ld_shadow;
+    p.adam.pk_stream = reinterpret_cast<uint16_t*>(a->pk_stream); p.adam.pk_K = a->pk_K; p.adam.pk_mode = a->pk_mode;
+    {
+      auto f = [](int c) { return (unsigned long long)(c < 0 || c >= 0xffff ? 0xffff : c); };
+      p.adam.pk_chunks = f(a->pk_chunk0[0]) | (f(a->pk_chunk0[1]) << 16) | (f(a->pk_chunk0[2]) << 32) | (f(a->pk_chunk0[3]) << 48);
+    }
+    p.adam.pk_row0 = a->pk_row0; p.adam.store_grad = a->store_grad;
+    p.adam.hyper = a->hyper; p.adam.step = a->step;
+  }
   p.waves8 = pl.waves8;
   p.split = pl.split;
   {
@@ -467,12 +496,13 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
   const int ok = check_desc(d);
   if (ok != VCT_OK) return ok;
   hipStream_t st = (hipStream_t)stream;
-  {
+  const bool general_only = d->adam != nullptr;      // the optimizer epilogue exists in the general bf16 kernel's dW form only
+  if (!general_only) {
     bool used = false;
     const int rcs = gemm_skinny_try(d, st, &used);
     if (rcs != VCT_OK || used) return rcs;
   }
-  {
+  if (!general_only) {
     bool used = false;
     int rsplit = 1;
     const int rc256 = gemm256_try(d, st, &used, &rsplit);
@@ -489,7 +519,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
     }
   }
 
-  {
+  if (!general_only) {
     bool used = false;
     const int rcp = gemm_pt_try(d, st, &used);
     if (rcp != VCT_OK || used) return rcp;
@@ -589,6 +619,10 @@ extern "C" int vct_gemm_grouped(const vct_gemm_desc* descs, int32_t n, void* str
   GemmGroupP g;
   g.n = n;
   int wg = 0;
+  // group-level XCD map (vct_gemm_bf16_kernel.h, gemm_bf16_v2_grouped_kernel) whenever no problem is split; VCT_GROUP_MAP=0: A/B
+  static const bool group_map_on = [] { const char* e = getenv("VCT_GROUP_MAP"); return !(e && e[0] == '0'); }();
+  bool group_map = group_map_on;
+  for (int i = 0; i < n && group_map; i++) group_map = grouped_plan(descs + i, t, gt).split == 1;
   for (int i = 0; i < n; i++) {
     const vct_gemm_desc* d = descs + i;
     const Plan pl = grouped_plan(d, t, gt);
@@ -598,9 +632,11 @@ extern "C" int vct_gemm_grouped(const vct_gemm_desc* descs, int32_t n, void* str
     }
     fill_params(d, pl, g.p[i]);
     g.start[i] = wg;
-    wg += (pl.tiles_m * pl.tiles_n * pl.split + 7) & ~7;
+    wg += group_map ? pl.tiles_m * pl.tiles_n : (pl.tiles_m * pl.tiles_n * pl.split + 7) & ~7;
   }
+  g.total = group_map ? wg : 0;
   for (int i = n; i < VCT_GEMM_GROUP_MAX; i++) { g.start[i] = wg; g.p[i] = g.p[0]; }
+  wg = (wg + 7) & ~7;
   const int rc = gemm_bf16_v2_grouped_tn(g, t.bm, t.bn, wg, (hipStream_t)stream);
   if (rc != VCT_OK) return rc;
   VCT_CHECK_LAUNCH();

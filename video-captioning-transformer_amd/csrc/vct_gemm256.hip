@@ -281,12 +281,8 @@ int persistent_grid(hipStream_t st) {
 }
 
 template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<TA, TB, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static vct::DynLdsOptIn optin;
+  if (hipError_t e = optin.ensure((const void*)gemm256_kernel<TA, TB, TO>, G256_LDS); e != hipSuccess) return (int)e;
   vct::launch(gemm256_kernel<TA, TB, TO>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;

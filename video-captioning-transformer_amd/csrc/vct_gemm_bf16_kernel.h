@@ -28,6 +28,7 @@
 #define VCT_GEMM_DMA_IL(TA, TB, BM, BN, NW) ((TA) == 0 && (TB) == 0)
 #endif
 #include "vct_common.h"
+#include "vct_adam_core.h"
 #include "vct_gemm_params.h"
 
 namespace vct {
@@ -210,7 +211,7 @@ __device__ __forceinline__ bf16x8 frag2(const unsigned char* lds, int r_base, in
 
 // One workgroup's tile of one GEMM: `bid` = workgroup index within the problem's tile grid, `zid` = K split.
 template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM, int WGN>
-__device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid, const int zid) {
+__device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid, const int zid, const bool direct = false) {
   constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
   constexpr bool KSPLIT = A_MC && B_MC;
   constexpr int NW = WGM * WGN, NT = 64 * NW;         // waves / threads per workgroup
@@ -230,6 +231,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
     const int xcd = bid & 7, local = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    if (direct) wgid = bid;          // the caller (grouped launch, group-level map) already placed this tile on its XCD
   }
   // Within an XCD's run, tiles are walked in groups of GRP along the LONGER tile dimension: the GRP
   // tiles' operand slabs stay L2-resident while the shorter dimension is swept, so each operand
@@ -450,9 +452,100 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   const bool vec_ok = (ldo % VO == 0) && (part || (((uintptr_t)p.C & 15) == 0));
   const int nt_store = p.nt_store;
   struct alignas(16) OutV { TO e[VO]; };
+  // Optimizer epilogue of the weight-gradient form (include/vct_hip.h, vct_gemm_adam): the gradient elements this lane would store
+  // are consumed by torch.optim.Adam's update of the parameter elements they belong to (same layout, same offset in the flat
+  // buffers), and the bf16 shadow / stream-order packed copy are written from the same registers -- the optimizer's 28 B per
+  // parameter move inside this MFMA-bound kernel (other workgroups of the CU are in their K loops meanwhile) instead of forming
+  // a serial HBM-bound tail of the step.  Shared by the direct path and the in-kernel split-K reduce, like `finish`.
+  AdamConsts hc;
+  bool adam_on = false;
+  // every field of the descriptor is read HERE, once, into locals: a branch on p.adam.<field> inside the unrolled epilogue makes
+  // hipcc copy the whole by-value group table (2.5 KB) into scratch in the grouped 128 x 128 kernel (the table is reached through the
+  // run-time problem index there)
+  float* ad_param = nullptr; float* ad_m = nullptr; float* ad_v = nullptr;
+  uint16_t* ad_shadow = nullptr; uint16_t* ad_pk = nullptr;
+  long ad_lds = 0; unsigned long long ad_chunks = 0ull;
+  int ad_mode = 0, ad_row0 = 0;
+  bool ad_store_grad = true;
+  const int ad_M = p.M, ad_N = p.N;
+  const long ad_ldc = p.ldc;
+  if constexpr (BG) {
+    adam_on = p.adam.param != nullptr;
+    if (adam_on) {
+      hc = adam_consts_uniform(p.adam.hyper, p.adam.step);
+      ad_param = p.adam.param; ad_m = p.adam.m; ad_v = p.adam.v;
+      ad_shadow = p.adam.shadow; ad_lds = p.adam.ld_shadow;
+      ad_pk = p.adam.pk_stream; ad_chunks = p.adam.pk_chunks; ad_mode = p.adam.pk_mode; ad_row0 = p.adam.pk_row0;
+      ad_store_grad = p.adam.store_grad != 0;
+    }
+  }
+  // Two halves so that the direct epilogue can put the loads of ALL the chunks of a tile row in flight before the first update (a
+  // chunk is three dependent HBM round trips otherwise: eight serial ones per wave and tile cost the vocabulary product +40 %):
+  //   adam_load  : parameter / moment vectors of a full chunk (addresses clamped into the matrix: unconditional loads)
+  //   adam_store : update + stores (parameters, moments, shadow, packed copy); ragged chunks take the element loop
+  struct AdamRegs { float4 p, m, v; };
+  auto adam_load = [&](const int row_in, const int col_in, AdamRegs& r) {
+    if constexpr (BG) {
+      // opaque copies: row / col depend on the thread index only, so without this every chunk's 64-bit addresses are computed at
+      // kernel entry and kept alive (spilled) across the K loop
+      int row = min(row_in, ad_M - 1), col = min(col_in, max(ad_N - 4, 0));
+      asm volatile("" : "+v"(row), "+v"(col));
+      const size_t e = (size_t)row * ad_ldc + col;
+      r.p = *reinterpret_cast<const float4*>(ad_param + e);
+      r.m = *reinterpret_cast<const float4*>(ad_m + e);
+      r.v = *reinterpret_cast<const float4*>(ad_v + e);
+    }
+  };
+  auto adam_store = [&](const int row_in, const int col_in, const float (&g)[VO], const bool full, AdamRegs& r) {
+    if constexpr (BG) {
+      int row = row_in, col = col_in;
+      asm volatile("" : "+v"(row), "+v"(col));
+      const size_t e = (size_t)row * ad_ldc + col;
+      if (full) {
+        static_assert(!BG || VO == 4, "fp32 output: four elements per lane chunk");
+        float* pp = &r.p.x; float* mp = &r.m.x; float* vp = &r.v.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) adam_update(pp[q], g[q], mp[q], vp[q], hc);
+        *reinterpret_cast<float4*>(ad_param + e) = r.p;
+        *reinterpret_cast<float4*>(ad_m + e) = r.m;
+        *reinterpret_cast<float4*>(ad_v + e) = r.v;
+        if (ad_shadow != nullptr) {
+          ushort4 o;
+          o.x = f2bf(r.p.x); o.y = f2bf(r.p.y); o.z = f2bf(r.p.z); o.w = f2bf(r.p.w);
+          *reinterpret_cast<ushort4*>(ad_shadow + (size_t)row * ad_lds + col) = o;
+          if (ad_pk != nullptr) {
+            const int64_t at = adam_pack_index(ad_row0 + row, col, ad_mode, ad_chunks);
+            if (at >= 0) *reinterpret_cast<ushort4*>(ad_pk + at) = o;
+          }
+        }
+      } else {
+        for (int q = 0; q < VO; q++) {
+          if (col + q >= ad_N) break;
+          float pv = ad_param[e + q], mv = ad_m[e + q], vv = ad_v[e + q];
+          adam_update(pv, g[q], mv, vv, hc);
+          ad_param[e + q] = pv; ad_m[e + q] = mv; ad_v[e + q] = vv;
+          if (ad_shadow != nullptr) {
+            const uint16_t o = f2bf(pv);
+            ad_shadow[(size_t)row * ad_lds + col + q] = o;
+            if (ad_pk != nullptr) {
+              const int64_t at = adam_pack_index(ad_row0 + row, col + q, ad_mode, ad_chunks);
+              if (at >= 0) ad_pk[at] = o;
+            }
+          }
+        }
+      }
+    }
+  };
+  auto adam_apply = [&](const int row, const int col, const float (&g)[VO], const bool full) {
+    if constexpr (BG) {
+      AdamRegs r;
+      if (full) adam_load(row, col, r);
+      adam_store(row, col, g, full, r);
+    }
+  };
   // bias / activation (+ saved pre-activation) / activation derivative / dropout / residual-gradient accumulate on
   // VO consecutive columns of one row, then the store -- shared by the direct path and the in-kernel split-K reduce
-  auto finish = [&](const int row, const int col, const float (&v)[VO], const float (&bv)[VO], const bool full) {
+  auto finish_store = [&](const int row, const int col, const float (&v)[VO], const float (&bv)[VO], const bool full) {
     if (full) {
       OutV dv, av, ov, pv;
       const bool has_d = dact != nullptr, has_a = addend != nullptr;
@@ -499,6 +592,17 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       }
     }
   };
+  // (ONE call site of finish_store: a second one in the direct loop sent the grouped kernel's whole argument table to scratch)
+  auto finish = [&](const int row, const int col, const float (&v)[VO], const float (&bv)[VO], const bool full, AdamRegs* pre) {
+    if constexpr (BG) {
+      if (adam_on) {
+        if (pre != nullptr && full) adam_store(row, col, v, true, *pre);      // state already in flight (direct epilogue)
+        else adam_apply(row, col, v, full);
+        if (!ad_store_grad) return;
+      }
+    }
+    finish_store(row, col, v, bv, full);
+  };
   static_for<TM>([&](auto I) {
     constexpr int i = decltype(I)::value;
     float* stage = stage_base + (NSLAB == 2 ? (i & 1) * STAGE_FLOATS : 0);
@@ -512,6 +616,16 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
       }
     });
     if constexpr (SLAB) lds_barrier();
+    AdamRegs areg[CPL];
+    const bool adam_direct = BG && adam_on && !part;
+    if constexpr (BG) {
+      if (adam_direct) {          // the optimizer state of every chunk of this tile row: in flight before the first update
+        static_for<CPL>([&](auto CI) {
+          constexpr int c = decltype(CI)::value;
+          adam_load(m0 + e_row[c] + i * 16, n0 + e_col[c], areg[c]);
+        });
+      }
+    }
     static_for<CPL>([&](auto CI) {
       constexpr int c = decltype(CI)::value;
       const int row = m0 + e_row[c] + i * 16, col = n0 + e_col[c];
@@ -541,7 +655,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
         }
         return;
       }
-      finish(row, col, v, bvec[c], full);
+      finish(row, col, v, bvec[c], full, adam_direct ? &areg[c] : nullptr);
     });
   });
 
@@ -585,7 +699,7 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
             for (int z = 0; z < p.split; z++) s[q] += coherent_load1(src + (size_t)z * zstride + q);
           }
         }
-        finish(row, col, s, bvec[c], full);
+        finish(row, col, s, bvec[c], full, nullptr);
       });
     });
     if (p.bias_grad != nullptr && tile_n == 0) {
@@ -612,18 +726,31 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, WGM * WGN)) 
 }
 
 // Several independent GEMMs of the same layout / tile shape in ONE launch (a layer's weight gradients): the
-// workgroup looks its problem up in a by-value table; each problem's run of workgroups starts at a multiple of 8
-// so that `bid & 7` is still the XCD the hardware dispatches the workgroup to.
+// workgroup looks its problem up in a by-value table.
+//   g.total > 0 (no problem is split): GROUP-level XCD map -- the tiles of all problems form ONE list (problem after problem, each in
+//   its own walk order: blocks of 8 x (short dimension) tiles), and XCD x = blockIdx & 7 owns a contiguous eighth of it, so the ~32
+//   tiles an XCD runs at the same time are one or two compact blocks of ONE or TWO problems that share their dY / X column panels
+//   through that XCD's L2 (a decoder layer: 12-16 panels of 1.25 MB per XCD instead of 35 when every problem is dealt out over all
+//   eight XCDs -- 366 MB of L2 misses per launch measured with the per-problem map, rocprofv3 TCC_EA0_RDREQ, round 5).
+//   g.total == 0: each problem's run of workgroups starts at a multiple of 8 (so that `bid & 7` is still the XCD) and is mapped on its own.
 template <typename TO, int TA, int TB, int BM, int BN, int NBUF, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, WGM * WGN)) void gemm_bf16_v2_grouped_kernel(const GemmGroupP g) {
   const int b = blockIdx.x;
+  int at = b;
+  const bool direct = g.total > 0;
+  if (direct) {
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = g.total >> 3, r = g.total & 7;
+    if (slot >= q + (xcd < r ? 1 : 0)) return;
+    at = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
   int gi = 0;
 #pragma unroll
-  for (int i = 1; i < VCT_GEMM_GROUP_MAX; i++) gi = (i < g.n && b >= g.start[i]) ? i : gi;
+  for (int i = 1; i < VCT_GEMM_GROUP_MAX; i++) gi = (i < g.n && at >= g.start[i]) ? i : gi;
   const GemmP& p = g.p[gi];
-  const int local = b - g.start[gi], nwg = p.tiles_m * p.tiles_n;
+  const int local = at - g.start[gi], nwg = p.tiles_m * p.tiles_n;
   if (local >= nwg * p.split) return;
-  gemm_bf16_v2_body<TO, TA, TB, BM, BN, NBUF, WGM, WGN>(p, local % nwg, local / nwg);
+  gemm_bf16_v2_body<TO, TA, TB, BM, BN, NBUF, WGM, WGN>(p, local % nwg, local / nwg, direct);
 }
 
 template <typename TO, int TA, int TB, int NBUF>

@@ -5,6 +5,18 @@
 
 namespace vct {
 
+// optimizer epilogue of the weight-gradient form (include/vct_hip.h, vct_gemm_adam); param == nullptr: off
+struct AdamEpiP {
+  float* param; float* m; float* v;
+  uint16_t* shadow; long ld_shadow;
+  uint16_t* pk_stream; int pk_K, pk_mode; int pk_row0; int store_grad;
+  // first chunk of the four 512-row blocks / 512-column slices as 16-bit fields (0xffff: not packed), selected by a SHIFT: an array
+  // member or four scalars + selects become an indexed load, and a run-time index into the by-value group table (reached through the
+  // problem index) puts the whole 2.5 KB table into scratch, per lane
+  unsigned long long pk_chunks;
+  const float* hyper; const int32_t* step;
+};
+
 struct GemmP {
   const void* A; const void* B; void* C;
   long lda, ldb, ldc;
@@ -27,11 +39,13 @@ struct GemmP {
   int nt_store;         // output store policy: 0 plain, 1 agent-scope streaming (vct_common.h), 2 non-temporal (experiments; default 0)
   int nt_preact;        // the saved pre-activation is not read again before the backward: non-temporal stores
   int short_fast;       // tile order: the SHORTER tile dimension runs fastest (tiles sharing a K-long operand slab are neighbours)
+  AdamEpiP adam;        // weight-gradient form only
 };
 
 struct GemmGroupP {
   int n;
-  int start[VCT_GEMM_GROUP_MAX];   // first workgroup of problem i (multiple of 8)
+  int total;                       // > 0: group-level XCD map over `total` tiles, start[] = tile prefix sums; 0: per-problem map
+  int start[VCT_GEMM_GROUP_MAX];   // first workgroup of problem i (a multiple of 8 in the per-problem map)
   GemmP p[VCT_GEMM_GROUP_MAX];
 };
 

@@ -290,12 +290,8 @@ __global__ __launch_bounds__(512, 4) void gemm_pt_kernel(const GemmP p) {
 
 template <int TA, int TB, int TM, int TN, bool EPI> static int gpt_launch(const GemmP& p, hipStream_t st) {
   constexpr int LDSB = 2 * (32 * TM + 64 * TN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static vct::DynLdsOptIn optin;
+  if (hipError_t e = optin.ensure((const void*)gemm_pt_kernel<TA, TB, TM, TN, EPI>, LDSB); e != hipSuccess) return (int)e;
   constexpr int per_cu = LDSB <= 80 * 1024 ? 2 : 1;
   vct::launch(gemm_pt_kernel<TA, TB, TM, TN, EPI>, dim3(per_cu * persistent_grid(st)), dim3(512), (size_t)LDSB, st, p);
   VCT_CHECK_LAUNCH();

@@ -466,14 +466,10 @@ extern "C" int vct_layer_ss_fwd(const vct_layer_ss_desc* layers, int n_layers, v
   hipStream_t st = (hipStream_t)stream;
   // rows <= 16: one 16-row MFMA tile per product (half the epilogue work, LDS reads and MFMAs of the two-tile form)
   const int one = q->L <= 16 ? 1 : 0, which = cross * 2 + one;
-  static bool attr_set[4] = {false, false, false, false};
+  static vct::DynLdsOptIn optin[4];
   const void* fn = which == 0 ? (const void*)layer_ss_fwd_kernel<false, 2> : which == 1 ? (const void*)layer_ss_fwd_kernel<false, 1>
                  : which == 2 ? (const void*)layer_ss_fwd_kernel<true, 2> : (const void*)layer_ss_fwd_kernel<true, 1>;
-  if (!attr_set[which]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set[which] = true;
-  }
+  if (hipError_t e = optin[which].ensure(fn, SS_LDS); e != hipSuccess) return (int)e;
   for (int base = 0; base < n_layers; base += SS_MAXL) {       // SS_MAXL layers per launch; the hand-over between launches goes through y in HBM
     const int nl = n_layers - base < SS_MAXL ? n_layers - base : SS_MAXL;
     SsLayerP p;

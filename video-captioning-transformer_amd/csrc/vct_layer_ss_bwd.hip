@@ -492,13 +492,9 @@ extern "C" int vct_layer_ss_bwd(const vct_layer_ss_bwd_desc* layers, int n_layer
   }
   hipStream_t st = (hipStream_t)stream;
   const int one = q->L <= 16 ? 1 : 0;
-  static bool attr_set[2] = {false, false};
+  static vct::DynLdsOptIn optin[2];
   const void* fn = one ? (const void*)layer_ss_bwd_kernel<1> : (const void*)layer_ss_bwd_kernel<2>;
-  if (!attr_set[one]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set[one] = true;
-  }
+  if (hipError_t e = optin[one].ensure(fn, SS_LDS); e != hipSuccess) return (int)e;
   SsBwdP p;
   memset(&p, 0, sizeof(p));
   p.B = q->B; p.L = q->L; p.ff = q->ff; p.act = q->act; p.last = q->last; p.causal = q->causal; p.nl = n_layers;

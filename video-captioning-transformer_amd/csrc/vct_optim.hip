@@ -4,7 +4,7 @@
 // Arithmetic follows torch.optim.Adam's single-tensor path (reference train.py:24-26,126):
 //   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // with bc = 1 - beta^t and t read from a DEVICE counter (the step stays hipGraph-capturable).
-#include "vct_common.h"
+#include "vct_adam_core.h"
 
 namespace vct {
 
@@ -19,14 +19,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, float wd, const int32_t* __restrict__ step,
                                                    int64_t skip_a, int64_t skip_b, const float* __restrict__ hyper,
                                                    const AdamPackSeg* __restrict__ segs, int nseg, int64_t base) {
-  // hyper-parameters from DEVICE memory when given: a captured hipGraph / recorded launch list then follows the
-  // learning-rate schedule (kernel arguments are frozen at capture time)
-  if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
-  const float t = (float)(step[0] + 1);
-  const float bc1 = 1.0f - powf(b1, t);
-  const float bc2s = sqrtf(1.0f - powf(b2, t));
-  const float step_size = lr / bc1;
-  const float decay = 1.0f - lr * wd;
+  const AdamConsts hc = adam_consts(lr, b1, b2, eps, wd, hyper, step);
   const int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -35,14 +28,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float4 vv = reinterpret_cast<float4*>(v)[i];
     float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float w = pp[j] * decay;
-      mp[j] = mp[j] + (1.0f - b1) * (gp[j] - mp[j]);
-      vp[j] = b2 * vp[j] + (1.0f - b2) * gp[j] * gp[j];
-      const float denom = sqrtf(vp[j]) / bc2s + eps;
-      w -= step_size * (mp[j] / denom);
-      pp[j] = w;
-    }
+    for (int j = 0; j < 4; j++) adam_update(pp[j], gp[j], mp[j], vp[j], hc);
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
@@ -59,15 +45,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         if (ef >= sg.begin && ef < sg.end) {
           const int64_t rel = ef - sg.begin;
           const int r = (int)(rel / sg.K), c = (int)(rel - (int64_t)r * sg.K);
-          const int blk = sg.mode == 0 ? (r >> 9) : (c >> 9);
-          const int nn = sg.mode == 0 ? (r & 511) : r, kk = sg.mode == 0 ? c : (c & 511);
-          const int ch0 = sg.chunk0[blk & 3];
-          if (blk < 4 && ch0 >= 0) {
-            // chunk = 64 columns of K; inside: wave nn / 64, tile (nn % 64) / 16, k-step, then lane = (k group, row % 16), 8 bf16 each
-            const int64_t vec = (int64_t)(ch0 + (kk >> 6)) * 4096 + (((nn >> 6) * 8 + ((nn & 63) >> 4) * 2 + ((kk & 63) >> 5)) * 64 +
-                                                                      ((kk & 31) >> 3) * 16 + (nn & 15));
-            *reinterpret_cast<ushort4*>(sg.stream + vec * 8 + (kk & 7)) = o;
-          }
+          const int64_t at = adam_pack_index(r, c, sg.mode, adam_pack_chunks(sg.chunk0[0], sg.chunk0[1], sg.chunk0[2], sg.chunk0[3]));
+          if (at >= 0) *reinterpret_cast<ushort4*>(sg.stream + at) = o;
         }
       }
     }
@@ -85,12 +64,7 @@ __global__ __launch_bounds__(256) void adam2d_kernel(float* __restrict__ p, cons
                                                      const int32_t* __restrict__ step, const float* __restrict__ hyper) {
   constexpr int STR = 72;                                    // LDS row stride in elements (16-byte aligned rows)
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * STR];
-  if (hyper != nullptr) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
-  const float t = (float)(step[0] + 1);
-  const float bc1 = 1.0f - powf(b1, t);
-  const float bc2s = sqrtf(1.0f - powf(b2, t));
-  const float step_size = lr / bc1;
-  const float decay = 1.0f - lr * wd;
+  const AdamConsts hc = adam_consts(lr, b1, b2, eps, wd, hyper, step);
   const int tiles_c = cols / 64;
   const int r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64, tid = threadIdx.x;
   float4 pv[4], gv[4], mv[4], vv[4];
@@ -106,14 +80,7 @@ __global__ __launch_bounds__(256) void adam2d_kernel(float* __restrict__ p, cons
     const int rl = (tid >> 4) + 16 * i, r = r0 + rl;
     float* pp = &pv[i].x; const float* gp = &gv[i].x; float* mp = &mv[i].x; float* vp = &vv[i].x;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float w = pp[j] * decay;
-      mp[j] = mp[j] + (1.0f - b1) * (gp[j] - mp[j]);
-      vp[j] = b2 * vp[j] + (1.0f - b2) * gp[j] * gp[j];
-      const float denom = sqrtf(vp[j]) / bc2s + eps;
-      w -= step_size * (mp[j] / denom);
-      pp[j] = w;
-    }
+    for (int j = 0; j < 4; j++) adam_update(pp[j], gp[j], mp[j], vp[j], hc);
     ushort4 o;
     o.x = f2bf(pv[i].x); o.y = f2bf(pv[i].y); o.z = f2bf(pv[i].z); o.w = f2bf(pv[i].w);
     *reinterpret_cast<ushort4*>(tile + rl * STR + (tid & 15) * 4) = o;
@@ -137,6 +104,53 @@ __global__ __launch_bounds__(256) void adam2d_kernel(float* __restrict__ p, cons
     bf16_t* dst = shadow_t + (int64_t)(c0 + cc) * ld_t + r;
     if (r + 8 <= rows) *reinterpret_cast<V8*>(dst) = o;
     else for (int j = 0; j < 8; j++) if (r + j < rows) dst[j] = o.e[j];
+  }
+}
+
+// The same step over a LIST of flat ranges in one launch: what is left of the parameter buffer when the weight matrices are stepped
+// inside their own weight-gradient GEMMs (vct_gemm_adam) -- biases, LayerNorm parameters, the token-embedding table, and any matrix
+// whose product did not take the epilogue.  ranges (device, sorted): [begin, end) flat elements (multiples of 4), blk0 = first
+// workgroup of the range (ADAM_RANGE_EPB elements per workgroup), shadow != 0: the bf16 shadow (and packed copies) follow.
+struct AdamRange { int64_t begin, end; int32_t blk0, shadow; };
+constexpr int ADAM_RANGE_EPB = 4096;
+__global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, bf16_t* __restrict__ shadow,
+                                                          const AdamRange* __restrict__ ranges, int nranges, float lr, float b1, float b2,
+                                                          float eps, float wd, const int32_t* __restrict__ step,
+                                                          const float* __restrict__ hyper, const AdamPackSeg* __restrict__ segs, int nseg) {
+  const AdamConsts hc = adam_consts(lr, b1, b2, eps, wd, hyper, step);
+  int lo = 0, hi = nranges;                                  // last range whose first workgroup is <= this one
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ranges[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const AdamRange rg = ranges[lo];
+  const int64_t e0 = rg.begin + (int64_t)((int)blockIdx.x - rg.blk0) * ADAM_RANGE_EPB;
+  const int64_t e1 = e0 + ADAM_RANGE_EPB < rg.end ? e0 + ADAM_RANGE_EPB : rg.end;
+  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
+    float4 pv = *reinterpret_cast<float4*>(p + e);
+    const float4 gv = *reinterpret_cast<const float4*>(g + e);
+    float4 mv = *reinterpret_cast<float4*>(m + e);
+    float4 vv = *reinterpret_cast<float4*>(v + e);
+    float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) adam_update(pp[j], gp[j], mp[j], vp[j], hc);
+    *reinterpret_cast<float4*>(p + e) = pv;
+    *reinterpret_cast<float4*>(m + e) = mv;
+    *reinterpret_cast<float4*>(v + e) = vv;
+    if (shadow != nullptr && rg.shadow) {
+      ushort4 o;
+      o.x = f2bf(pv.x); o.y = f2bf(pv.y); o.z = f2bf(pv.z); o.w = f2bf(pv.w);
+      *reinterpret_cast<ushort4*>(shadow + e) = o;
+      if (nseg > 0) {
+        int slo = 0, shi = nseg;
+        while (shi - slo > 1) { const int mid = (slo + shi) >> 1; if (segs[mid].begin <= e) slo = mid; else shi = mid; }
+        const AdamPackSeg sg = segs[slo];
+        if (e >= sg.begin && e < sg.end) {
+          const int64_t rel = e - sg.begin;
+          const int r = (int)(rel / sg.K), c = (int)(rel - (int64_t)r * sg.K);
+          const int64_t at = adam_pack_index(r, c, sg.mode, adam_pack_chunks(sg.chunk0[0], sg.chunk0[1], sg.chunk0[2], sg.chunk0[3]));
+          if (at >= 0) *reinterpret_cast<ushort4*>(sg.stream + at) = o;
+        }
+      }
+    }
   }
 }
 
@@ -177,6 +191,21 @@ extern "C" int vct_adam_step_pk(float* param, const float* grad, float* exp_avg,
     vct::launch(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
     VCT_CHECK_LAUNCH();
   }
+  return VCT_OK;
+}
+
+extern "C" int vct_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                    const vct_adam_range* ranges_dev, int32_t nranges, int32_t total_blocks, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t* step_dev, const float* hyper_dev,
+                                    const vct_adam_pack_seg* segs_dev, int32_t nseg, void* stream) {
+  static_assert(sizeof(vct_adam_range) == sizeof(AdamRange), "descriptor layout");
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || !ranges_dev || nranges < 1 || total_blocks < 1) return VCT_E_ARG;
+  if (nseg < 0 || (nseg > 0 && (segs_dev == nullptr || shadow_bf16 == nullptr))) return VCT_E_ARG;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VCT_E_ALIGN;
+  vct::launch(adam_ranges_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+              (bf16_t*)shadow_bf16, reinterpret_cast<const AdamRange*>(ranges_dev), (int)nranges, lr, beta1, beta2, eps, weight_decay,
+              step_dev, hyper_dev, reinterpret_cast<const AdamPackSeg*>(segs_dev), (int)nseg);
+  VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
 

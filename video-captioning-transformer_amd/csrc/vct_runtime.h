@@ -25,6 +25,21 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: a process that drives several GPUs must opt in on each of them (a
+// once-per-process flag left the > 64 KB launches of the second device failing).  One bit per device per call site.
+struct DynLdsOptIn {
+  unsigned long long done[4] = {0, 0, 0, 0};      // up to 256 devices
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 256 && ((done[dev >> 6] >> (dev & 63)) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
+    return e;
+  }
+};
+
 inline hipError_t memset_async(void* p, int value, size_t bytes, hipStream_t st) {
   if (g_rec != nullptr) {
     rec_push(st, [=](hipStream_t s) { const hipError_t e = hipMemsetAsync(p, value, bytes, s); if (e != hipSuccess) replay_note_error((int)e); });

@@ -89,6 +89,10 @@ class ParamSet:
         # sample-stationary layer kernels (ops.layer_ss_fwd), kept in step with the shadow exactly like the eager transposed copies
         self.packed = {}
         self._adam_pack = {}
+        # the optimizer that steps weight matrices INSIDE their weight-gradient GEMMs (trainer.FusedAdam.enable_dw_fusion; None: nobody
+        # does): _StackBase.dw_gemm asks it for the epilogue descriptor of every gradient view it is about to produce
+        self.dw_adam = None
+        self._starts = None
         # MFMA-fragment-major copies of single decoder weights (name -> [tensor, version]): operands of the batched block decode
         # (ops.decode_bblock), refreshed on demand like the lazy transposed copies (decode entry points)
         self.fragpacked = {}
@@ -180,6 +184,10 @@ class ParamSet:
                 b = max(self.offsets[n] + self.params[n].numel() for n in names)
                 subs.append([a, b, blocks, True])
             ent = self.packed[key] = [t, firsts, subs]
+            # a NEW stream changes what a step launches (the optimizer's pass / the pack launch behind it now also writes this
+            # stream): recordings made before it existed would replay without refreshing it -> drop them (ctx.generation is what
+            # CaptionTrainer keys its launch lists / graphs on)
+            self.ctx.generation += 1
         todo = []
         for sub in ent[2]:
             if sub[3]:
@@ -212,6 +220,21 @@ class ParamSet:
                 ops.pack_frag(self.c[name], ent[0])
                 ent[1] = self.version
 
+    def name_at(self, off: int):
+        """(parameter name, its first flat element) of the parameter that holds flat element `off`."""
+        import bisect
+        if self._starts is None:
+            self._starts = sorted((o, n) for n, o in self.offsets.items())
+        i = bisect.bisect_right(self._starts, (off, chr(0x10ffff))) - 1
+        return self._starts[i][1], self._starts[i][0]
+
+    def pack_seg(self, name: str):
+        """(K, mode, [chunk0 x 4], stream pointer) of the stream-order packed copy the optimizer can maintain for the weight `name`
+        (adam_pack_table's eligibility rules), or None."""
+        _t, _n, _parts = self.adam_pack_table(0, self.total)
+        sg = self._adam_pack[(0, self.total, tuple(sorted(self.packed)))][3].get(name)
+        return None if sg is None else (sg[2], sg[3], list(sg[4]), sg[5])
+
     def adam_pack_table(self, a: int, b: int):
         """(device table of vct_adam_pack_seg, entries, [parts]) for the packed parts whose weights lie inside flat elements [a, b):
         the optimizer's pass over [a, b) writes their stream-order copies itself (ops.adam_step(pack=...)).  Parts with transposed
@@ -220,7 +243,7 @@ class ParamSet:
         key = (a, b, tuple(sorted(self.packed)))
         hit = self._adam_pack.get(key)
         if hit is not None:
-            return hit
+            return hit[:3]
         import bisect
         starts = sorted((off, n) for n, off in self.offsets.items())
         segs, parts = {}, []
@@ -251,6 +274,9 @@ class ParamSet:
                     else:
                         ok = False
                         break
+                    if name in segs and segs[name][5] != ent[0].data_ptr():
+                        ok = False            # another stream already holds this weight: the kernel's table has ONE stream per weight,
+                        break                 # so this part stays with vct_ss_pack (refresh_transposed) instead of going stale
                     sg = mine.setdefault(name, [mo, mo + N * K, K, mode, [-1, -1, -1, -1], ent[0].data_ptr()])
                     if sg[3] != mode:
                         ok = False
@@ -270,8 +296,8 @@ class ParamSet:
             table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         else:
             table = None
-        hit = self._adam_pack[key] = (table, len(rows), parts)
-        return hit
+        hit = self._adam_pack[key] = (table, len(rows), parts, segs)
+        return hit[:3]
 
     def refresh_transposed(self, a: int, b: int, skip=(), packed_done=()):
         """Shadow elements [a, b) were just rewritten: eager transposed copies inside follow (except `skip`: already written by
@@ -398,13 +424,22 @@ class _StackBase:
 
     def dw_gemm(self, dy, x, dw, *, bias_grad=None, m_valid=None, tag=None):
         """dw[M,N] (fp32 gradient view) = dy^T x, bias_grad[M] = column sums of dy."""
+        ad = self.dw_adam_desc(dy, dw)
         if self.group_dw and m_valid is None and tag is None and dy.dtype == torch.bfloat16:
-            self._dw_pending.append((dy, x, dw, bias_grad))
+            self._dw_pending.append((dy, x, dw, bias_grad, ad))
             if len(self._dw_pending) == ops.L.GEMM_GROUP_MAX:
                 self.flush_dw()
             return
         self._on_side(lambda ws: ops.gemm(dy, x, dw, ta=True, tb=False, bias_grad=bias_grad, m_valid=m_valid, tag=tag,
-                                          workspace=ws))
+                                          workspace=ws, adam=ad))
+
+    def dw_adam_desc(self, dy, dw):
+        """Epilogue descriptor (ops.L.GemmAdam) when the optimizer steps this weight inside the GEMM that produces its gradient
+        `dw` (single GPU, trainer.FusedAdam.enable_dw_fusion), else None."""
+        opt = self.ps.dw_adam
+        if opt is None or dy.dtype != torch.bfloat16 or self.dev.type != "cuda":
+            return None
+        return opt.desc_for(dw)
 
     def flush_dw(self, main: bool = False):
         """Issue the queued weight-gradient GEMMs as one grouped launch (side stream, or the current one if `main`)."""
@@ -1033,7 +1068,10 @@ class DecoderEngine(_StackBase):
         kpm = ("ids", ids, pad)          # tgt_padding_mask[:, :-1] == (ids[:, :Sd] == pad), evaluated inside the attention kernel
         b.t["kpm"] = kpm
         self._wgt = None
-        if training and self.gen_dx_nt and self.dt == torch.bfloat16 and self.dev.type == "cuda":
+        if training and self.gen_dx_nt and self.dt == torch.bfloat16 and self.dev.type == "cuda" and self.ps.dw_adam is None:
+            # (Not with the optimizer inside the vocabulary weight-gradient GEMM: an epilogue that also emitted W_g^T -- per-wave LDS
+            # transposition, 16-byte pieces of the transposed rows -- took that product from 328 to 413 us for a dX that is 40 us
+            # faster in the NT form; round 5, gpurun_out/r5f.  dX then runs in its NN form.)
             # dX = dlogits W_g in the K-contiguous NT form (persistent 256x256 kernel, split over K): needs W_g^T, which the
             # parameter set keeps beside the bf16 shadow -- rewritten right after the optimizer has touched W_g (62 MB of traffic
             # in the main stream's slack at the end of the step), not here in front of the latency-bound layer stack
@@ -1090,14 +1128,14 @@ class DecoderEngine(_StackBase):
         if early_gen_dw:      # A/B: right behind the dX GEMM on the main stream, alone on the chip (nothing runs on the side stream yet)
             defer_gen_dw = False
             ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
-                     tag="gen_dw", workspace=self.gemm_ws())
+                     tag="gen_dw", workspace=self.gemm_ws(), adam=self.dw_adam_desc(dl, self.G("generator.weight")))
 
         def gen_dw():
             if early_gen_dw:
                 return
             if defer_gen_dw:
                 ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
-                         tag="gen_dw", workspace=self.gemm_ws())
+                         tag="gen_dw", workspace=self.gemm_ws(), adam=self.dw_adam_desc(dl, self.G("generator.weight")))
             else:
                 self.dw_gemm(dl, y, self.G("generator.weight"), bias_grad=self.G("generator.bias"), m_valid=self.V, tag="gen_dw")
         if not defer_gen_dw:
@@ -1123,11 +1161,19 @@ class DecoderEngine(_StackBase):
                 ops.sync_record(dmem_point)
                 # the bottom layer's weight gradients run on the MAIN stream (whose tail is not the critical path any
                 # more): the side stream is free for the encoder backward the moment d(memory) is final
-                self.flush_dw(main=self.l0_dw_main & 1 != 0)
+                # (With the optimizer inside the weight-gradient GEMMs this group REWRITES the layer's weights, W_kv among them, which
+                # the layer's d(memory) product -- queued on the SIDE stream -- reads: the group then waits for the end of the layer's
+                # chain, where the main stream first joins the side stream; tests/test_executor_gpu.py delays the side stream to show it.)
+                if self.ps.dw_adam is None:
+                    self.flush_dw(main=self.l0_dw_main & 1 != 0)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, Bn, Sd, Sd, True, kpm, site + 1, True, ds1)
             if l == 0 and on_dmem_ready is not None:
-                self.flush_dw(main=self.l0_dw_main & 2 != 0)
+                if self.ps.dw_adam is not None and self.side is not None and self.overlap_dw and self.l0_dw_main:
+                    ops.stream_wait(None, self.side)          # the d(memory) products are behind us: one group of seven on the main stream
+                    self.flush_dw(main=True)
+                else:
+                    self.flush_dw(main=self.l0_dw_main & 2 != 0)
                 if bucket_ready is not None:
                     self.flush_ln_grads(b)
                     # through the side stream like every other bucket: the hook's optimizer step REWRITES this layer's weights (and

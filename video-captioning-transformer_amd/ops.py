@@ -35,8 +35,10 @@ class GemmScratch:
 
 
 def _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
-               n_valid, k_valid, m_valid):
+               n_valid, k_valid, m_valid, adam=None):
     d = L.GemmDesc()
+    if adam is not None:      # L.GemmAdam: optimizer epilogue of the weight-gradient form (the caller keeps it alive through the call)
+        d.adam = L.C.pointer(adam)
     d.dtype, d.out_dtype = L.dtype_code(a.dtype), L.dtype_code(out.dtype)
     assert b.dtype == a.dtype
     d.ta, d.tb = int(ta), int(tb)
@@ -78,14 +80,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
          addend: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None, dropout: Drop = None,
          bias_grad: Optional[torch.Tensor] = None, workspace=None, split_k: int = 0,
          n_valid: Optional[int] = None, k_valid: Optional[int] = None, m_valid: Optional[int] = None,
-         tag: Optional[str] = None, tile: int = 0) -> torch.Tensor:
+         tag: Optional[str] = None, tile: int = 0, adam=None) -> torch.Tensor:
     """out[M,N] = epilogue(op(a) @ op(b)).  ta=False: a is [M,K]; ta=True: a is [K,M].
     tb=True: b is [N,K] (nn.Linear weight); tb=False: b is [K,N].  n_valid / k_valid override the
     logical N / K when a buffer is wider than its valid extent (zero-padded vocabulary columns).
-    workspace: a fp32 tensor (two-pass split-K) or a GemmScratch (single-pass split-K)."""
+    workspace: a fp32 tensor (two-pass split-K) or a GemmScratch (single-pass split-K).
+    adam: L.GemmAdam (weight-gradient form only) -- torch.optim.Adam's step on the matrix runs in the epilogue (include/vct_hip.h)."""
     lib = L.load()
     d = _gemm_desc(a, b, out, ta, tb, bias, act, preact, addend, dact_src, dropout, bias_grad, workspace, split_k,
-                   n_valid, k_valid, m_valid)
+                   n_valid, k_valid, m_valid, adam)
     d.reserved = tile       # kernel selection override (include/vct_hip.h, vct_gemm_desc.reserved): tests and A/B probes
     timed = _taps_on and tag in TAPS and (_taps_only is None or tag in _taps_only)
     if timed:
@@ -97,15 +100,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, ta: bool = Fals
 
 
 def gemm_grouped(items, scratch: GemmScratch, split_k: int = 0, tile: int = 0):
-    """One launch for up to 8 weight-gradient GEMMs: items = [(dy [rows,M], x [rows,N], dW [M,N] fp32, db [M] fp32 or None)]
-    -> dW = dy^T x, db = column sums of dy (include/vct_hip.h, vct_gemm_grouped)."""
+    """One launch for up to 8 weight-gradient GEMMs: items = [(dy [rows,M], x [rows,N], dW [M,N] fp32, db [M] fp32 or None[, L.GemmAdam or None])]
+    -> dW = dy^T x, db = column sums of dy (include/vct_hip.h, vct_gemm_grouped); with a GemmAdam the optimizer steps the matrix in
+    the epilogue."""
     lib = L.load()
     n = len(items)
     if not 1 <= n <= L.GEMM_GROUP_MAX:
         raise ValueError(f"gemm_grouped: 1..{L.GEMM_GROUP_MAX} problems per launch, got {n}")
     arr = (L.GemmDesc * n)()
-    for i, (dy, x, dw, db) in enumerate(items):
-        d = _gemm_desc(dy, x, dw, True, False, None, None, None, None, None, None, db, None, split_k, None, None, None)
+    for i, it in enumerate(items):
+        dy, x, dw, db = it[:4]
+        d = _gemm_desc(dy, x, dw, True, False, None, None, None, None, None, None, db, None, split_k, None, None, None,
+                       it[4] if len(it) > 4 else None)
         C_ = L.C
         C_.memmove(C_.byref(arr[i]), C_.byref(d), C_.sizeof(L.GemmDesc))
     arr[0].reserved = tile
@@ -226,6 +232,54 @@ def ss_pack(blocks, dst: torch.Tensor):
         segs[i].transposed = int(tr)
     L.check(L.load().vct_ss_pack(segs, n, dst.data_ptr(), L.stream_ptr()), "vct_ss_pack")
     return dst
+
+
+def rp_linear_supported(N: int, K: int, epi: int) -> bool:
+    return bool(L.load().vct_rp_linear_supported(L.BF16, int(N), int(K), int(epi)))
+
+
+def rp_pack_transposed(w: torch.Tensor, dst: torch.Tensor = None) -> torch.Tensor:
+    """The stream vct_rp_linear reads for dX = dY W: W = an nn.Linear weight (or a row slice of one) [K = out rows, N = in columns], bf16,
+    as N / 512 transposed blocks of K / 64 chunks each (include/vct_hip.h, vct_rp_linear / vct_ss_pack)."""
+    K, N = w.shape
+    assert N % 512 == 0 and K % 64 == 0 and w.stride(1) == 1 and w.dtype == torch.bfloat16
+    nch = K // 64
+    if dst is None:
+        dst = torch.empty((N // 512) * nch * 32768, dtype=torch.bfloat16, device=w.device)
+    return ss_pack([(w[:, 512 * j:], nch, j * nch, True) for j in range(N // 512)], dst)
+
+
+def rp_linear(dy, wpk, N, *, out=None, addend=None, hpre=None, act="gelu", site=0, seed=None, p_drop=0.0, norm=None):
+    """Row-panel Linear backward (include/vct_hip.h, vct_rp_linear): dX[M, N] = epilogue(dy[M, K] W), W given as the packed transposed
+    stream `wpk` (rp_pack_transposed).  hpre -> epi 1 (activation derivative + dropout mask of the feed-forward), norm = dict(gamma,
+    mean, rstd, ws, xs, res, ds, dxo, site) -> epi 2 (LayerNorm backward), else epi 0.  Replaces ops.gemm(dy, W) (+ ops.add_ln_bwd)."""
+    q = L.RpLinearDesc()
+    M, K = dy.shape
+    epi = 2 if norm is not None else 1 if hpre is not None else 0
+    q.dtype, q.M, q.N, q.K, q.epi, q.act = L.BF16, int(M), int(N), int(K), epi, L.ACT[act]
+    assert dy.dtype == torch.bfloat16 and dy.stride(1) == 1
+    q.A, q.lda, q.wpk = dy.data_ptr(), dy.stride(0), wpk.data_ptr()
+    if out is not None:
+        assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.shape == (M, N)
+        q.out, q.ldo = out.data_ptr(), out.stride(0)
+    if addend is not None:
+        assert addend.dtype == torch.bfloat16 and addend.stride(1) == 1 and addend.shape == (M, N)
+        q.addend, q.ld_addend = addend.data_ptr(), addend.stride(0)
+    if hpre is not None:
+        assert hpre.dtype == torch.bfloat16 and hpre.stride(1) == 1 and hpre.shape == (M, N)
+        q.hpre, q.ld_hpre = hpre.data_ptr(), hpre.stride(0)
+    q.seed, q.site, q.p_drop = L.ptr(seed), int(site), float(p_drop if seed is not None else 0.0)
+    if norm is not None:
+        n = q.norm
+        for k in ("gamma", "mean", "rstd", "ws", "xs", "ds"):
+            setattr(n, k, norm[k].data_ptr())
+        for k in ("xs", "ds", "res", "dxo"):
+            t = norm.get(k)
+            assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape == (M, 512))
+        n.res, n.dxo, n.site = L.ptr(norm.get("res")), L.ptr(norm.get("dxo")), int(norm.get("site", 0))
+        assert norm["ws"].numel() >= ((M + 31) // 32) * 2 * 512 and norm["ws"].dtype == torch.float32
+    L.check(L.load().vct_rp_linear(q, L.stream_ptr()), "vct_rp_linear")
+    return out if norm is None else norm["ds"]
 
 
 def layer_ss_bwd_stream_chunks(ff: int) -> int:
@@ -509,6 +563,32 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, w
                                    param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    step_dev.data_ptr(), int(skip[0]), int(skip[1]), int(bool(bump)), L.ptr(hyper), L.stream_ptr()),
             "vct_adam_step")
+
+
+def adam_ranges_table(ranges, device):
+    """Device table for adam_step_ranges: ranges = sorted [(begin, end, has_shadow)] of flat elements (multiples of 4).
+    Returns (table tensor, entries, workgroups)."""
+    EPB = 4096
+    arr = (L.AdamRange * len(ranges))()
+    blk = 0
+    for i, (a, b, sh) in enumerate(ranges):
+        assert a % 4 == 0 and b % 4 == 0 and b > a
+        arr[i].begin, arr[i].end, arr[i].blk0, arr[i].shadow = int(a), int(b), blk, int(bool(sh))
+        blk += (b - a + EPB - 1) // EPB
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return table, len(ranges), blk
+
+
+def adam_step_ranges(param, grad, exp_avg, exp_avg_sq, shadow, table, lr, beta1, beta2, eps, weight_decay, step_dev, hyper=None, pack=None):
+    """vct_adam_step over a LIST of ranges of the WHOLE flat buffers in one launch (table from adam_ranges_table): what is left for a
+    separate pass when the weight matrices are stepped inside their weight-gradient GEMMs.  pack = (device table of
+    vct_adam_pack_seg with flat indices, entries) or None.  No step-counter bump."""
+    tab, n, blocks = table
+    pk, nseg = (pack[0].data_ptr(), int(pack[1])) if pack is not None and pack[1] else (0, 0)
+    L.check(L.load().vct_adam_step_ranges(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), L.ptr(shadow),
+                                          tab.data_ptr(), int(n), int(blocks), float(lr), float(beta1), float(beta2), float(eps),
+                                          float(weight_decay), step_dev.data_ptr(), L.ptr(hyper), pk, nseg, L.stream_ptr()),
+            "vct_adam_step_ranges")
 
 
 def adam_step_2d(param, grad, exp_avg, exp_avg_sq, shadow, shadow_t, lr, beta1, beta2, eps, weight_decay, step_dev, hyper=None):

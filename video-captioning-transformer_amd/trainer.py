@@ -214,6 +214,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper_host = None
         self.sync_hyper()
         self.pre_state_dict = None      # set by ShardedExchange: all-gather the moments before they are read (collective)
+        # weight matrices stepped INSIDE their weight-gradient GEMMs (enable_dw_fusion): flat ranges registered by desc_for() while the
+        # backward of the current step is being enqueued; step_range() then covers only what is left
+        self.dw_fusion = False
+        self._dw_ranges = []
+        self._dw_desc = {}
+        self._range_tables = {}
 
     def _hyper_now(self):
         g = self.param_groups[0]
@@ -226,6 +232,75 @@ class FusedAdam(torch.optim.Optimizer):
         if h != self._hyper_host:
             self.hyper[:5].copy_(torch.tensor(h, dtype=torch.float32))
             self._hyper_host = h
+
+    # ---- the optimizer inside the weight-gradient GEMMs (single GPU) ---------------------------------------------------------------
+    # A/B switch.  The reference steps every parameter after backward (train.py:125-126); on one GPU nothing sits between a weight's
+    # gradient and its update, so the update of every 2-D weight runs in the epilogue of the GEMM that produces the gradient
+    # (include/vct_hip.h, vct_gemm_adam): the gradient never goes to HBM and the optimizer's 28 B per parameter move inside MFMA-bound
+    # kernels instead of forming a 0.3 ms HBM-bound tail of the step.  What is left (biases, LayerNorm parameters, the embedding
+    # table) takes ONE multi-range launch per step_range() call.
+    fuse_dw_default = os.environ.get("VCT_FUSE_ADAM", "1") != "0"
+    keep_grads = os.environ.get("VCT_FUSE_ADAM_KEEP_GRAD", "0") == "1"      # also store the weight gradients (hooks / inspection)
+
+    def enable_dw_fusion(self, on: bool = True):
+        """Called by CaptionTrainer when it owns the whole step (no gradient exchange).  bf16 compute mode on a GPU only."""
+        ps = self.model._ps
+        ok = bool(on) and ps.compute_dtype == torch.bfloat16 and ps.flat.is_cuda
+        self.dw_fusion = ok
+        ps.dw_adam = self if ok else None
+        self._dw_ranges = []
+        return ok
+
+    def begin_step(self):
+        """Forget the matrices registered by the previous enqueue of a step (the set is rebuilt as the backward is enqueued)."""
+        self._dw_ranges = []
+
+    def desc_for(self, dw: torch.Tensor):
+        """ops.L.GemmAdam for the weight whose gradient view `dw` (fp32 [rows, K], rows of one parameter) a GEMM is about to
+        produce, and note that this step's step_range() calls must leave its flat range alone.  None: not steppable there."""
+        ps = self.model._ps
+        off = (dw.data_ptr() - ps.gflat.data_ptr()) // 4
+        if not self.dw_fusion or dw.dim() != 2 or dw.dtype != torch.float32 or not (0 <= off < self.end):
+            return None
+        name, base = ps.name_at(off)
+        shape = ps.params[name].shape
+        rows, K = dw.shape
+        if len(shape) != 2 or K != shape[1] or dw.stride(0) != K or dw.stride(1) != 1 or (off - base) % K or name in ps.no_shadow:
+            return None
+        key = (off, rows, tuple(sorted(ps.packed)))
+        ad = self._dw_desc.get(key)
+        if ad is None:
+            ad = ops.L.GemmAdam()
+            ad.param, ad.exp_avg, ad.exp_avg_sq = (t.data_ptr() + 4 * off for t in (ps.flat, self.exp_avg, self.exp_avg_sq))
+            ad.shadow, ad.ld_shadow = ps.cflat.data_ptr() + 2 * off, K
+            seg = ps.pack_seg(name)
+            if seg is not None:
+                ad.pk_K, ad.pk_mode, ad.pk_stream, ad.pk_row0 = seg[0], seg[1], seg[3], (off - base) // K
+                for i in range(4):
+                    ad.pk_chunk0[i] = seg[2][i]
+            ad.hyper, ad.step = self.hyper.data_ptr(), self.step_dev.data_ptr()
+            ad.store_grad = int(self.keep_grads)
+            self._dw_desc[key] = ad
+        self._dw_ranges.append((off, off + rows * K))
+        return ad
+
+    def _left_ranges(self, a: int, b: int):
+        """[(begin, end, has_shadow)] of [a, b) minus the matrices registered for this step, split at the shadow-less tensors."""
+        cuts = sorted(set((max(x, a), min(y, b)) for x, y in self._dw_ranges if y > a and x < b))
+        out, cur = [], a
+        for x, y in cuts:
+            if x > cur:
+                out.append((cur, x))
+            cur = max(cur, y)
+        if cur < b:
+            out.append((cur, b))
+        res = []
+        s0, s1 = self.skip
+        for x, y in out:                      # the embedding table has no bf16 shadow
+            for lo, hi, sh in ((x, min(y, s0), True), (max(x, s0), min(y, s1), False), (max(x, s1), y, True)):
+                if hi > lo:
+                    res.append((lo, hi, sh))
+        return res
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -247,6 +322,20 @@ class FusedAdam(torch.optim.Optimizer):
         lr, b1, b2, eps, wd = self._hyper_now()
         ps = self.model._ps
         bf = ps.compute_dtype != torch.float32
+        if self.dw_fusion and self._dw_ranges:
+            # the matrices of [a, b) were stepped by their weight-gradient GEMMs (which also wrote their shadows and packed copies): one
+            # launch over what is left -- vectors, the embedding table, any matrix whose GEMM did not take the epilogue
+            left = self._left_ranges(a, b)
+            table, nseg, pk_parts = ps.adam_pack_table(a, b) if (self.pack_in_adam and ps.packed) else (None, 0, [])
+            if left:
+                key = (tuple(left), )
+                tab = self._range_tables.get(key)
+                if tab is None:
+                    tab = self._range_tables[key] = ops.adam_ranges_table(left, ps.flat.device)
+                ops.adam_step_ranges(ps.flat, ps.gflat, self.exp_avg, self.exp_avg_sq, ps.cflat, tab, lr, b1, b2, eps, wd, self.step_dev,
+                                     hyper=self.hyper, pack=(table, nseg) if nseg else None)
+            ps.refresh_transposed(a, b, packed_done=pk_parts)
+            return
         # 2-D weights with an eager transposed shadow inside the range (W_g^T): their own pass writes the transposed copy too
         fused = sorted(ps.eager_transposed_in(a, b), key=lambda x: x[2]) if bf else []
         fused = [f for f in fused if ps.params[f[0]].shape[1] % 64 == 0 and not (f[2] < self.skip[1] and f[3] > self.skip[0])]
@@ -386,11 +475,26 @@ class CaptionTrainer:
         # optimizer pass steals HBM bandwidth from the GEMMs it overlaps), so it is opt-in; with a gradient exchange
         # Adam always runs per bucket as each all-reduce lands (it overlaps the wire, not the GEMMs)
         self.overlap_adam = False
+        # single GPU, FusedAdam, bf16: every weight matrix is stepped in the epilogue of its own weight-gradient GEMM (FusedAdam.
+        # enable_dw_fusion); the hook is installed only WHILE this trainer enqueues a step (a plain loss.backward() outside it must
+        # keep producing gradients and nothing else)
+        self.fuse_adam = bool(single and isinstance(optimizer, FusedAdam) and optimizer.fuse_dw_default
+                              and model._ps.compute_dtype == torch.bfloat16 and model.flat_grads.is_cuda)
 
     # A/B switch (single GPU): the whole Adam pass after the joined backward instead of 86 % of it beside the encoder backward
     adam_after_backward = os.environ.get("VCT_ADAM_TAIL", "0") == "1"
 
     def _step_kernels(self, feats, mask, ids):
+        if not self.fuse_adam:
+            return self._step_kernels_body(feats, mask, ids)
+        self.opt.enable_dw_fusion(True)
+        self.opt.begin_step()
+        try:
+            return self._step_kernels_body(feats, mask, ids)
+        finally:
+            self.opt.enable_dw_fusion(False)
+
+    def _step_kernels_body(self, feats, mask, ids):
         m = self.model
         fused = isinstance(self.opt, FusedAdam)
         ops.tap("step", 0)
