@@ -231,7 +231,6 @@ def main():
     ap.add_argument("--no-overlap-dw", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-overlap-kv", action="store_true", help="A/B: cross-attention K/V projections and d(memory) GEMMs on the main stream")
     ap.add_argument("--no-overlap-enc", action="store_true", help="A/B: encoder backward after (not beside) the decoder's tail")
-    ap.add_argument("--fuse-attn", action="store_true", help="A/B: attention core + out_proj + add-LayerNorm as ONE launch (vct_attn_block_fwd)")
     ap.add_argument("--no-group-dw", action="store_true", help="A/B: one launch per weight-gradient GEMM instead of one per layer")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
@@ -268,9 +267,6 @@ def main():
         MMT4Caption.overlap_dec_prefix = False
     if os.environ.get("VCT_NO_DEC_PREFIX"):
         MMT4Caption.overlap_dec_prefix = False
-    if args.fuse_attn:
-        from vct_amd import engine as _eng
-        _eng._StackBase.fuse_attn_block = True
     if args.no_group_dw:
         from vct_amd import engine as _eng
         _eng._StackBase.group_dw = False

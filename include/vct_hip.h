@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 12
+#define VCT_ABI_VERSION 13
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -156,66 +156,6 @@ int vct_attn_fwd(const vct_attn_desc* d, void* stream);
 int vct_attn_bwd(const vct_attn_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused attention block forward (bf16): y = LayerNorm(res + dropout(attn_core(q,k,v) W_out^T + b_out)), ONE launch,
- * one workgroup per batch element, one wave per head; the attention output goes from registers through LDS into the
- * output projection (W_out streamed from L2 straight into MFMA B fragments), bias / dropout / residual / LayerNorm in
- * the epilogue (csrc/vct_attn_block.hip).
- * replaces: the SDPA core + out_proj nn.Linear + dropout + residual add + nn.LayerNorm of every attention block of
- * nn.TransformerEncoderLayer / nn.TransformerDecoderLayer (torch nn/modules/transformer.py:951-957,1143-1167; built at
- * MMEncoder.py:236-238, CapDecoder.py:18-20) -- i.e. vct_attn_fwd + vct_gemm + vct_add_ln_fwd of the unfused path.
- *   attn: as vct_attn_fwd (attn.o = attention output [B*Lq, H*hd], saved for the out_proj weight gradient; attn.seed /
- *   p_drop / site = dropout on the attention probabilities; batch strides must be 0).
- *   w_out bf16 [d, d] (nn.Linear layout [out, in]), b_out fp32 [d], res bf16 [B*Lq, d], gamma / beta fp32 [d].
- *   a_out bf16: out_proj output BEFORE dropout (what vct_add_ln_bwd re-reads as `x`), y bf16, mean / rstd fp32 [B*Lq].
- *   site_res: dropout site of the residual dropout (seed and p of attn).  d = H*hd.
- * The saved tensors and dropout streams equal the unfused kernels', so the unfused backward kernels run behind it.
- * vct_attn_block_supported: 1 when the shape is covered (bf16; H=8,hd=64 or H=4,hd in {16,32}; Lq <= 32; LDS budget).
- * --------------------------------------------------------------------------------------------- */
-typedef struct vct_attn_block_desc {
-  vct_attn_desc attn;
-  const void* w_out; int64_t ldw;
-  const float* b_out;
-  const void* res; int64_t ld_res;
-  const float* gamma; const float* beta;
-  void* a_out; int64_t ld_a;
-  void* y; int64_t ld_y;
-  float* mean; float* rstd;
-  uint32_t site_res; int32_t reserved;
-} vct_attn_block_desc;
-int vct_attn_block_supported(int dtype, int H, int hd, int Lq, int Lk);
-int vct_attn_block_fwd(const vct_attn_block_desc* d, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Row-complete nn.Linear + dropout + residual + LayerNorm (+ optional second LayerNorm) in ONE launch (bf16):
- *     a = x W^T + bias  (x [M,K], W [d,K]);  y = LayerNorm(res + dropout(a));  y2 = LayerNorm2(y) when gamma2 != NULL.
- * replaces: out_proj (torch nn/functional.py:6637) / linear2 + dropoutN + residual add + normN of an encoder / decoder layer
- * (torch nn/modules/transformer.py:951-957,980-982,1143-1167,1197-1199, built at MMEncoder.py:236-238, CapDecoder.py:18-20)
- * and, with gamma2, the stack-final LayerNorm (MMEncoder.py:238, CapDecoder.py:20) -- vct_gemm + vct_add_ln_fwd
- * (+ vct_add_ln_fwd) on the unfused path.  Saves exactly what those save: a_out (bf16 a, may be NULL), mean / rstd
- * (fp32 [M]), y; the dropout counter stream is vct_add_ln_fwd's (site, row * d + col), so the unfused backward kernels
- * run unchanged behind it.  res may be NULL.  rows_per_wg: 0 = automatic, 16 or 32.
- * vct_linear_ln_supported: 1 when (dtype, d, K) is covered (bf16, d = 512, K a multiple of 64).
- * --------------------------------------------------------------------------------------------- */
-typedef struct vct_linear_ln_desc {
-  int32_t dtype, M, d, K;
-  const void* x; int64_t ldx;
-  const void* w; int64_t ldw;
-  const float* bias;
-  const void* res; int64_t ld_res;
-  const uint32_t* seed; uint32_t site; float p_drop;
-  const float* gamma; const float* beta;
-  void* a_out; int64_t ld_a;
-  void* y; int64_t ld_y;
-  float* mean; float* rstd;
-  const float* gamma2; const float* beta2;
-  void* y2; int64_t ld_y2;
-  float* mean2; float* rstd2;
-  int32_t rows_per_wg, reserved;
-} vct_linear_ln_desc;
-int vct_linear_ln_supported(int dtype, int d, int K);
-int vct_linear_ln_fwd(const vct_linear_ln_desc* d, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
  * Sample-stationary Transformer stack forward (bf16): ONE launch = up to 4 whole encoder / decoder layers (and, with last != 0
  * in the last descriptor, the stack-final LayerNorm); one 512-thread workgroup per SAMPLE keeps that sample's rows in LDS
  * from the first layer's input to the last layer's output and streams the weights from L2 straight into MFMA operand
@@ -335,40 +275,6 @@ int vct_ln_ws_rows(int M);
  * n_entries LayerNorms in ONE launch.  table_dev: DEVICE int64 [n_entries][4] = {param_ws ptr, dgamma ptr,
  * dbeta ptr, vct_ln_ws_rows(M)} (every param_ws must stay untouched until then). */
 int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Row-panel Linear backward (bf16, csrc/vct_rowpanel.hip): the input-gradient product of an nn.Linear of the layers' dX chain
- *     dX[M, N] = epilogue(dY[M, K] W),   W = the Linear's weight [out = K, in = N],  N a multiple of 512
- * with a workgroup per 32-row panel that keeps its dY rows in LDS and reads W as the TRANSPOSED stream-order packed blocks of
- * vct_ss_pack (block j = rows [512 j, 512 j + 512) of W^T: segment {w = W + 512 j, ldw = N, nchunks = K / 64, transposed = 1},
- * blocks back to back).  Complete rows per workgroup make the row-wise op behind the product an epilogue:
- *   epi 0: out = acc (+ addend)                                       -- out_proj / q / k|v projections' input gradients
- *   epi 1: out = acc * act'(hpre) * dropout-mask(site, row * N + col) -- linear2's input gradient = gradient of the pre-activation
- *   epi 2: LayerNorm backward of the norm whose OUTPUT the Linear read (post-norm layers): gy = acc + addend, then exactly
- *          vct_add_ln_bwd(dy = gy, x = norm.xs, res = norm.res, ...): ds, dxo (NULL = not stored), and one (dgamma | dbeta)
- *          partial row pair per panel in norm.ws [ceil(M / 32)][2][512] fp32 (vct_ln_param_finalize_batched sums them: rows = panels)
- * replaces: the autograd nodes of F.linear / F.gelu / nn.Dropout / nn.LayerNorm inside nn.TransformerEncoderLayer /
- * nn.TransformerDecoderLayer (torch nn/modules/transformer.py:951-982,1143-1199; built at MMEncoder.py:236-238, CapDecoder.py:18-20)
- * run by `loss.backward()` (train.py:125) -- i.e. one vct_gemm (ta = 0, tb = 0) + one vct_add_ln_bwd launch of the unfused schedule.
- * vct_rp_linear_supported: bf16, N % 512 == 0 (epi 0 / 2: N == 512), K % 128 == 0, LDS <= 160 KiB.
- * --------------------------------------------------------------------------------------------- */
-typedef struct vct_rp_norm_bwd {
-  const float* gamma; const float* mean; const float* rstd; float* ws;
-  const void* xs; const void* res; void* ds; void* dxo;
-  uint32_t site, reserved;
-} vct_rp_norm_bwd;
-typedef struct vct_rp_linear_desc {
-  int32_t dtype, M, N, K, epi, act;
-  const void* A; int64_t lda;
-  const void* wpk;
-  void* out; int64_t ldo;
-  const void* addend; int64_t ld_addend;
-  const void* hpre; int64_t ld_hpre;
-  const uint32_t* seed; uint32_t site; float p_drop;
-  vct_rp_norm_bwd norm;
-} vct_rp_linear_desc;
-int vct_rp_linear_supported(int dtype, int N, int K, int epi);
-int vct_rp_linear(const vct_rp_linear_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder front end after the `unify` GEMM: z[b,0] = mean_t u[b,t] (all T rows, pads included),
@@ -589,44 +495,6 @@ typedef struct vct_decode_block_desc {
 } vct_decode_block_desc;
 int vct_decode_block_supported(int dtype, int d, int H, int ff, int Lk);
 int vct_decode_block(const vct_decode_block_desc* d, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Batched greedy-decode step, ONE launch per decoder-layer block (bf16, 2 <= batch <= 256, d = 512, 8 heads): the batch-1 block design
- * (vct_decode_block) on 16-row MFMA tiles (csrc/vct_decode_bblock.hip).
- * replaces: CapDecoder.decode_word's module calls for all captions of the batch at one position (reference model/CapDecoder.py:62-79,
- * called from MMT4Caption.py:163-166; torch nn/modules/transformer.py:1143-1199) -- the 8 launches per layer of the
- * vct_decode_linear / vct_attn_fwd path.
- *   kind 0 self-attention block   grid (8 heads, B/16): rows x = prologue; q | k | v of head h -> cache slot; attention over the Lk
- *                                 cached positions (the last one = this step's); partial out-projection -> part_out[h]
- *   kind 1 cross-attention block  the same with the q projection only; keys / values = the memory's (computed once per decode)
- *   kind 2 feed-forward block     grid (ff/256, B/16): act(x W1[256 rows]^T + b1) -> partial x W2[:, 256 cols]^T -> part_out[c]
- *   kind 3 closing rows           y_out (bf16) = prologue rows (norm3 + decoder.norm over the last block's partials)
- * prologue: x[row] = table[ids[row*id_stride]] + pos_row (ids != NULL), else res[row] (+ res_bias) + sum_{c < n_part} part[c][row]
- *   (part[c] = part + c*part_stride, rows of 512 fp32), then LayerNorm(g1, b1) and LayerNorm(g2, b2) where given; the workgroups
- *   with blockIdx.x == 0 store x to x_out (fp32, the next block's residual).
- * w_a / w_b: FRAGMENT-MAJOR packed weights (vct_pack_frag): dst[(tile*ksteps + s)*512 + lane*8 + j] =
- *   W[16*tile + (lane & 15)][32*s + (lane >> 4)*8 + j].  kind 0: w_a = packed in_proj_weight [1536, 512], a_tile = {0, 32, 64};
- *   kind 1: w_a = packed in_proj_weight (rows 0..511 used), a_tile[0] = 0; w_b = packed out_proj.weight (b_ksteps = 16);
- *   kind 2: w_a = packed linear1.weight, w_b = packed linear2.weight (b_ksteps = ff/32).  b_a = the first product's bias.
- * slot (kind 0): q | k | v of the consumed token, row (m) at slot + m*slot_bs; kc / vc: cached keys / values, position j of row m at
- *   kc + m*kv_bs + j*kv_ld (+ head*64).  Lk <= 64.
- * vct_decode_bblock_supported: bf16, d = 512, H = 8, ff a multiple of 256 and <= 2048, B <= 256, Lk <= 64.
- * --------------------------------------------------------------------------------------------- */
-typedef struct vct_decode_bblock_desc {
-  int32_t kind, B, ff, Lk, act, b_ksteps;
-  int32_t a_tile[3]; int32_t n_part;
-  const int64_t* ids; int64_t id_stride; const float* table; const float* pos_row;
-  const float* res; int64_t ld_res; const float* res_bias; const float* part; int64_t part_stride;
-  const float* g1; const float* b1; const float* g2; const float* b2;
-  float* x_out; int64_t ld_xout;
-  const void* w_a; const float* b_a; void* slot; int64_t slot_bs;
-  const void* kc; const void* vc; int64_t kv_ld; int64_t kv_bs;
-  const void* w_b; float* part_out; int64_t part_out_stride;
-  void* y_out; int64_t ld_y;
-} vct_decode_bblock_desc;
-int vct_decode_bblock_supported(int dtype, int d, int H, int ff, int B, int Lk);
-int vct_decode_bblock(const vct_decode_bblock_desc* d, void* stream);
-int vct_pack_frag(const void* w, int64_t ldw, int rows, int cols, void* dst, void* stream);
 
 /* seed[0] += 1 (one-thread kernel, keeps the dropout stream advancing inside a captured graph) */
 int vct_advance_seed(uint32_t* seed, void* stream);

@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 13
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 
@@ -84,15 +84,11 @@ int main(void) {
          sizeof(vct_attn_desc), offsetof(vct_attn_desc, d_o), offsetof(vct_attn_desc, q_bs));
   printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_desc), offsetof(vct_layer_ss_desc, wpk), offsetof(vct_layer_ss_desc, n2),
          offsetof(vct_layer_ss_desc, key_pad), offsetof(vct_layer_ss_desc, site_n3), sizeof(vct_ss_pack_seg), offsetof(vct_ss_pack_seg, dst_chunk));
-  printf("%zu %zu %zu %zu\\n", sizeof(vct_decode_bblock_desc), offsetof(vct_decode_bblock_desc, ids), offsetof(vct_decode_bblock_desc, w_a),
-         offsetof(vct_decode_bblock_desc, ld_y));
   printf("%zu %zu %zu %zu %zu\\n", sizeof(vct_layer_ss_bwd_desc), offsetof(vct_layer_ss_bwd_desc, wpk), offsetof(vct_layer_ss_bwd_desc, n3),
          offsetof(vct_layer_ss_bwd_desc, key_pad), offsetof(vct_layer_ss_bwd_desc, site_n3));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vct_gemm_adam), offsetof(vct_gemm_adam, shadow), offsetof(vct_gemm_adam, pk_stream),
          offsetof(vct_gemm_adam, pk_chunk0), offsetof(vct_gemm_adam, store_grad), offsetof(vct_gemm_adam, step), offsetof(vct_gemm_desc, adam),
          sizeof(vct_adam_range));
-  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vct_rp_linear_desc), offsetof(vct_rp_linear_desc, wpk), offsetof(vct_rp_linear_desc, hpre),
-         offsetof(vct_rp_linear_desc, p_drop), offsetof(vct_rp_linear_desc, norm), sizeof(vct_rp_norm_bwd));
   return 0;
 }''')
     exe = tmp_path / "sz"
@@ -102,14 +98,10 @@ int main(void) {
     S, P = _lib.LayerSsDesc, _lib.SsPackSeg
     assert got == [ctypes.sizeof(G), G.workspace.offset, G.tile_counters.offset, ctypes.sizeof(A), A.d_o.offset, A.q_bs.offset,
                    ctypes.sizeof(S), S.wpk.offset, S.n2.offset, S.key_pad.offset, S.site_n3.offset, ctypes.sizeof(P), P.dst_chunk.offset,
-                   ctypes.sizeof(_lib.DecodeBBlockDesc), _lib.DecodeBBlockDesc.ids.offset, _lib.DecodeBBlockDesc.w_a.offset,
-                   _lib.DecodeBBlockDesc.ld_y.offset,
                    ctypes.sizeof(_lib.LayerSsBwdDesc), _lib.LayerSsBwdDesc.wpk.offset, _lib.LayerSsBwdDesc.n3.offset,
                    _lib.LayerSsBwdDesc.key_pad.offset, _lib.LayerSsBwdDesc.site_n3.offset,
                    ctypes.sizeof(_lib.GemmAdam), _lib.GemmAdam.shadow.offset, _lib.GemmAdam.pk_stream.offset, _lib.GemmAdam.pk_chunk0.offset,
-                   _lib.GemmAdam.store_grad.offset, _lib.GemmAdam.step.offset, G.adam.offset, ctypes.sizeof(_lib.AdamRange),
-                   ctypes.sizeof(_lib.RpLinearDesc), _lib.RpLinearDesc.wpk.offset, _lib.RpLinearDesc.hpre.offset, _lib.RpLinearDesc.p_drop.offset,
-                   _lib.RpLinearDesc.norm.offset, ctypes.sizeof(_lib.RpNormBwd)]
+                   _lib.GemmAdam.store_grad.offset, _lib.GemmAdam.step.offset, G.adam.offset, ctypes.sizeof(_lib.AdamRange)]
 
 
 def test_layer_ss_entry_points_validate_arguments(lib_path):
@@ -147,14 +139,6 @@ def test_layer_ss_entry_points_validate_arguments(lib_path):
     assert lib.vct_adam_step_pk(p, p, p, p, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, p, 1, 0, None) == -1
     assert lib.vct_adam_step_pk(p, p, p, p, p, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, p, 1, 2, None) == -1
     assert lib.vct_adam_step_pk(p, p, p, p, p, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 0, 0, 0, None, None, -1, 0, None) == -1
-    # batched block decode (csrc/vct_decode_bblock.hip)
-    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 128, 30) == 1
-    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 4096, 128, 30) == 0 and lib.vct_decode_bblock_supported(_lib.BF16, 768, 8, 2048, 128, 30) == 0
-    assert lib.vct_decode_bblock_supported(_lib.BF16, 512, 8, 2048, 257, 30) == 0 and lib.vct_decode_bblock_supported(_lib.F32, 512, 8, 2048, 16, 30) == 0
-    assert lib.vct_decode_bblock(None, None) == -1 and lib.vct_pack_frag(None, 512, 512, 512, None, None) == -1
-    bd = _lib.DecodeBBlockDesc()
-    bd.kind, bd.B = 0, 16
-    assert lib.vct_decode_bblock(bd, None) == -1                                    # no input rows
 
 
 def test_no_cpu_fallback_when_library_is_missing(monkeypatch, lib_path):

@@ -193,18 +193,16 @@ def test_cfgB_greedy_decode_batch128_vs_oracle():
     assert n > 0.9 * ref_ys.size
 
 
-@pytest.mark.parametrize("B,path", [(1, "block"), (1, "gemv"), (16, "bblock"), (16, "skinny"), (128, "bblock"), (128, "skinny"), (37, "bblock")])
+@pytest.mark.parametrize("B,path", [(1, "block"), (1, "gemv"), (16, "skinny"), (128, "skinny"), (37, "skinny")])
 def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
     """The bf16 token step that bench.py times -- batch 1: weight-streaming matrix-vector kernels (vct_decode_gemv / vct_decode_block),
-    batch >= 2: one launch per layer block on 16-row MFMA tiles (vct_decode_bblock, the default) or skinny MFMA projections with
-    LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
+    batch >= 2: skinny MFMA projections with LayerNorm prologues (vct_decode_linear) -- run through the KV cache along the reference's
     caption: the predicted next id must be the reference's wherever its top-2 logit margin is resolvable in bf16 (> 0.15),
     over >= 9 positions.  Batch 1 / 16: ids and margins recorded from the reference (cfgB_decode.npz); batch 128: the oracle.
     Batch 1 runs both of its kernels: one launch per layer block (vct_decode_block, the default) and one per stage (vct_decode_gemv)."""
     from vct_amd import decode, engine
     if path == "gemv":
         monkeypatch.setattr(engine.DecoderEngine, "block_decode", False)
-    monkeypatch.setattr(engine.DecoderEngine, "bblock_decode", path == "bblock")      # (off by default: measured slower, engine.py)
     z = load_golden("cfgB_decode.npz")
     mc, V = model_config_of(z), int(z["vocab"])
     cfg = O.cfg_from_model_config(mc, V)
@@ -226,7 +224,6 @@ def test_cfgB_bf16_kv_cache_step_teacher_forced(B, path, monkeypatch):
         assert engine._decoder_block_decode_ok(dec, st) == (path == "block") and engine._decoder_small_decode_ok(dec, st)
     else:
         assert engine._decoder_fused_decode_ok(dec, st) and not engine._decoder_small_decode_ok(dec, st)
-        assert engine._decoder_bblock_decode_ok(dec, st) == (path == "bblock")
     feats = torch.from_numpy(f).to(DEV)
     ref = torch.from_numpy(np.ascontiguousarray(ref_ys[:, :steps + 1])).to(DEV)
     nxt, lgb = decode.teacher_forced_next_ids(mb, feats, None, ref, steps, return_logits=True)

@@ -151,23 +151,6 @@ def test_taps_time_kernels_inside_replays():
         ops.taps_enable(False)
 
 
-def test_fused_attention_block_in_the_training_step(monkeypatch):
-    """engine._StackBase.fuse_attn_block (off by default: no gain at cfg-B) swaps three launches per attention block for
-    vct_attn_block_fwd; loss and gradients of a step must agree with the unfused schedule to bf16 rounding."""
-    from vct_amd import engine
-    out = {}
-    for fused in (False, True):
-        monkeypatch.setattr(engine._StackBase, "fuse_attn_block", fused)
-        m = _model(torch.bfloat16, dropout=0.3, seed=11)
-        m._seed.fill_(77)
-        loss = m.train_step_kernels(*_batch(21)).clone()
-        torch.cuda.synchronize()
-        out[fused] = (float(loss), m.flat_grads.clone())
-    assert abs(out[True][0] - out[False][0]) < 2e-3 * abs(out[False][0])
-    g0, g1 = out[False][1].double(), out[True][1].double()
-    assert float((g1 - g0).norm() / g0.norm()) < 3e-2
-
-
 @pytest.mark.parametrize("sharded", [True, False])
 @pytest.mark.parametrize("executor", ["eager", "list"])
 def test_own_rccl_communicator_world1_step_is_the_plain_step(sharded, executor):

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -48,20 +48,6 @@ class AttnDesc(C.Structure):
                 ("key_ids", vp), ("key_ids_bs", i64), ("pad_id", i64)]
 
 
-class AttnBlockDesc(C.Structure):
-    _fields_ = [("attn", AttnDesc), ("w_out", vp), ("ldw", i64), ("b_out", vp), ("res", vp), ("ld_res", i64),
-                ("gamma", vp), ("beta", vp), ("a_out", vp), ("ld_a", i64), ("y", vp), ("ld_y", i64),
-                ("mean", vp), ("rstd", vp), ("site_res", u32), ("reserved", i32)]
-
-
-class LinearLnDesc(C.Structure):
-    _fields_ = [("dtype", i32), ("M", i32), ("d", i32), ("K", i32), ("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("bias", vp),
-                ("res", vp), ("ld_res", i64), ("seed", vp), ("site", u32), ("p_drop", f32), ("gamma", vp), ("beta", vp),
-                ("a_out", vp), ("ld_a", i64), ("y", vp), ("ld_y", i64), ("mean", vp), ("rstd", vp),
-                ("gamma2", vp), ("beta2", vp), ("y2", vp), ("ld_y2", i64), ("mean2", vp), ("rstd2", vp),
-                ("rows_per_wg", i32), ("reserved", i32)]
-
-
 class SsNorm(C.Structure):
     _fields_ = [("gamma", vp), ("beta", vp), ("y", vp), ("mean", vp), ("rstd", vp)]
 
@@ -88,17 +74,6 @@ class AdamPackSeg(C.Structure):
 
 class SsBwdNorm(C.Structure):
     _fields_ = [("gamma", vp), ("mean", vp), ("rstd", vp), ("ws", vp)]
-
-
-class RpNormBwd(C.Structure):
-    _fields_ = [("gamma", vp), ("mean", vp), ("rstd", vp), ("ws", vp), ("xs", vp), ("res", vp), ("ds", vp), ("dxo", vp),
-                ("site", u32), ("reserved", u32)]
-
-
-class RpLinearDesc(C.Structure):
-    _fields_ = [("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("epi", i32), ("act", i32), ("A", vp), ("lda", i64), ("wpk", vp),
-                ("out", vp), ("ldo", i64), ("addend", vp), ("ld_addend", i64), ("hpre", vp), ("ld_hpre", i64),
-                ("seed", vp), ("site", u32), ("p_drop", f32), ("norm", RpNormBwd)]
 
 
 class LayerSsBwdDesc(C.Structure):
@@ -135,14 +110,6 @@ class DecodeBlockDesc(C.Structure):
                 ("sel_ws", vp), ("tok_out", vp), ("end_id", i64), ("ended", vp), ("ended_count", vp), ("all_ended_at", vp), ("t", i32), ("pad1", i32)]
 
 
-class DecodeBBlockDesc(C.Structure):
-    _fields_ = [("kind", i32), ("B", i32), ("ff", i32), ("Lk", i32), ("act", i32), ("b_ksteps", i32), ("a_tile", i32 * 3), ("n_part", i32),
-                ("ids", vp), ("id_stride", i64), ("table", vp), ("pos_row", vp), ("res", vp), ("ld_res", i64), ("res_bias", vp),
-                ("part", vp), ("part_stride", i64), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("x_out", vp), ("ld_xout", i64),
-                ("w_a", vp), ("b_a", vp), ("slot", vp), ("slot_bs", i64), ("kc", vp), ("vc", vp), ("kv_ld", i64), ("kv_bs", i64),
-                ("w_b", vp), ("part_out", vp), ("part_out_stride", i64), ("y_out", vp), ("ld_y", i64)]
-
-
 DEC_PRO = {"none": 0, "embed": 1, "ln": 2, "ln_ln": 3, "self_attn": 4, "cross_attn": 5}
 
 _SIGS = {
@@ -154,18 +121,12 @@ _SIGS = {
     "vct_gemm_grouped_workspace_bytes": (i64, [C.POINTER(GemmDesc), i32, i32]),
     "vct_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "vct_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
-    "vct_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "vct_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), vp]),
     "vct_layer_ss_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_layer_ss_stream_chunks": (i64, [C.c_int, C.c_int]),
     "vct_ss_pack": (C.c_int, [C.POINTER(SsPackSeg), C.c_int, vp, vp]),
     "vct_layer_ss_fwd": (C.c_int, [C.POINTER(LayerSsDesc), C.c_int, vp]),
-    "vct_rp_linear_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "vct_rp_linear": (C.c_int, [C.POINTER(RpLinearDesc), vp]),
     "vct_layer_ss_bwd_stream_chunks": (i64, [C.c_int]),
     "vct_layer_ss_bwd": (C.c_int, [C.POINTER(LayerSsBwdDesc), C.c_int, vp]),
-    "vct_linear_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "vct_linear_ln_fwd": (C.c_int, [C.POINTER(LinearLnDesc), vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
@@ -182,9 +143,6 @@ _SIGS = {
     "vct_decode_gemv": (C.c_int, [C.POINTER(DecodeGemvDesc), vp]),
     "vct_decode_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vct_decode_block": (C.c_int, [C.POINTER(DecodeBlockDesc), vp]),
-    "vct_decode_bblock_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "vct_decode_bblock": (C.c_int, [C.POINTER(DecodeBBlockDesc), vp]),
-    "vct_pack_frag": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp]),
     "vct_decode_linear": (C.c_int, [C.POINTER(DecodeLinearDesc), vp]),
     "vct_decode_ln2": (C.c_int, [C.c_int, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "vct_advance_seed": (C.c_int, [vp, vp]),

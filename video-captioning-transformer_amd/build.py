@@ -9,7 +9,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvct_hip.so")
-SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_gemm256.hip", "vct_gemm_pt.hip", "vct_gemm_skinny.hip", "vct_attn.hip", "vct_attn_block.hip", "vct_layer_ss.hip", "vct_layer_ss_bwd.hip", "vct_rowpanel.hip", "vct_linear_ln.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_decode.hip", "vct_decode_block.hip", "vct_decode_bblock.hip", "vct_runtime.hip", "vct_comm.hip"]
+SOURCES = ["vct_gemm.hip", "vct_gemm_bf16.hip", "vct_gemm_bf16_nt.hip", "vct_gemm_bf16_nn.hip", "vct_gemm_bf16_tn.hip", "vct_gemm256.hip", "vct_gemm_pt.hip", "vct_gemm_skinny.hip", "vct_attn.hip", "vct_layer_ss.hip", "vct_layer_ss_bwd.hip", "vct_norm.hip", "vct_elem.hip", "vct_optim.hip", "vct_decode.hip", "vct_decode_block.hip", "vct_runtime.hip", "vct_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

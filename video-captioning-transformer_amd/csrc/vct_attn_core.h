@@ -1,6 +1,5 @@
-// Shared device code of the attention kernels (vct_attn.hip: one wave per (batch, head) per workgroup;
-// vct_attn_block.hip: one workgroup per batch element, one wave per head, fused with the output projection and the
-// residual LayerNorm).  See vct_attn.hip for the algorithm notes.
+// Shared device code of the attention kernels (vct_attn.hip: one to four waves per (batch, head); the sample-stationary layer kernels'
+// in-LDS attention builds on the same helpers).  See vct_attn.hip for the algorithm notes.
 #pragma once
 #include "vct_common.h"
 

@@ -109,11 +109,14 @@ extern "C" int vct_comm_init(const uint8_t* id128, int rank, int world, void** o
   static const char* prio_env = getenv("VCT_COMM_PRIO");
   // VCT_COMM_CU_MASK=N (bench.py --comm-cu-mask N): confine the collectives' kernels to the first N CUs (hipExtStreamCreateWithCUMask;
   // only "first N" masks take effect on this runtime, tools/cu_mask_probe2.py) so that RCCL cannot spread over the compute
-  // streams' CUs.  Unmeasured at N > 1 ranks (1-GPU boxes): an experiment switch for the driver's scaling run.
+  // streams' CUs.  Unmeasured at N > 1 ranks (1-GPU boxes): an experiment switch for the driver's scaling run.  NOTE: the masked
+  // stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags): unlike the other two branches it synchronizes
+  // implicitly with the NULL stream -- nothing of this library runs on the NULL stream, but the A/B changes that as well as placement.
   const char* mask_env = getenv("VCT_COMM_CU_MASK");
   const int mask_n = mask_env != nullptr ? atoi(mask_env) : 0;
+  if (mask_env != nullptr && (mask_n < 1 || mask_n > 255)) { delete c; return VCT_E_ARG; }   // a mask that cannot be applied is an error, not a silent no-op
   hipError_t e;
-  if (mask_n > 0 && mask_n < 256) {
+  if (mask_n > 0) {
     uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int cu = 0; cu < mask_n; cu++) words[cu >> 5] |= 1u << (cu & 31);
     e = hipExtStreamCreateWithCUMask(&c->stream, 8, words);

@@ -93,9 +93,6 @@ class ParamSet:
         # does): _StackBase.dw_gemm asks it for the epilogue descriptor of every gradient view it is about to produce
         self.dw_adam = None
         self._starts = None
-        # MFMA-fragment-major copies of single decoder weights (name -> [tensor, version]): operands of the batched block decode
-        # (ops.decode_bblock), refreshed on demand like the lazy transposed copies (decode entry points)
-        self.fragpacked = {}
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
         self.cast_ranges, start = [], 0
         for n in self.names:
@@ -197,17 +194,6 @@ class ParamSet:
             ops.ss_pack(todo, ent[0])
         return ent[0], ent[1]
 
-    def want_fragpack(self, name: str) -> torch.Tensor:
-        """The 2-D weight `name` in MFMA-fragment-major order (include/vct_hip.h, vct_pack_frag), created on first use and re-packed
-        HERE or by refresh_lazy_transposed() when the shadow has changed since (`version`)."""
-        ent = self.fragpacked.get(name)
-        if ent is None:
-            ent = self.fragpacked[name] = [torch.empty(self.c[name].numel(), dtype=self.compute_dtype, device=self.device), -1]
-        if ent[1] != self.version:
-            ops.pack_frag(self.c[name], ent[0])
-            ent[1] = self.version
-        return ent[0]
-
     def refresh_lazy_transposed(self):
         """Bring every on-demand transposed copy up to date (decode entry points call this before replaying captured steps,
         which bake the copies' addresses but cannot notice that the weights moved on)."""
@@ -215,10 +201,6 @@ class ParamSet:
             if not ent[3] and ent[4] != self.version:
                 ops.transpose(self.c[name], ent[0])
                 ent[4] = self.version
-        for name, ent in self.fragpacked.items():
-            if ent[1] != self.version:
-                ops.pack_frag(self.c[name], ent[0])
-                ent[1] = self.version
 
     def name_at(self, off: int):
         """(parameter name, its first flat element) of the parameter that holds flat element `off`."""
@@ -499,54 +481,13 @@ class _StackBase:
         ops.gemm(o, self.W(lp + "out_proj.weight"), a, bias=self.F(lp + "out_proj.bias"))
         return a
 
-    # attention core + out_proj + dropout + residual + LayerNorm in ONE launch (vct_attn_block_fwd).  Measured at cfg-B
-    # (tools/attn_block_bench.py): 31.9 us fused vs 28.1 us for the three kernels -- its phases are additive (launch +
-    # epilogue 12.1, attention 8.5, projection 11.3 us) because one 8-wave workgroup per CU leaves nothing to overlap them
-    # with, so the unfused kernels stay the default; the fused block is kept (tested) for larger per-CU concurrency.
-    fuse_attn_block = False
-
-    # out_proj + dropout + residual + LayerNorm as ONE row-complete launch (vct_linear_ln_fwd) behind the attention core.
-    # Measured at cfg-B: ALONE (tools/linear_ln_bench.py, recorded replays) it wins -- decoder rows 17.2 -> 13.8 us, encoder rows
-    # 14.0 -> 10.9 us per block -- but IN THE STEP it does not: same-box A/B 2.432 (unfused) vs 2.443 ms (fused), twice; the
-    # kernel's profile time there is 20.6 us against 12.7 alone.  One workgroup per CU with 136 KB of LDS shuts out whatever the
-    # other stream would co-schedule (the decoder prefix beside the encoder), like the 256-tile weight gradient did in round 2.
-    # The same kernel with linear2 (K = ff = 2048) loses even alone (36 vs 28 us: every workgroup streams the whole 2 MB weight
-    # at the L2 -> LDS rate of one CU).  Kept (tested) behind this switch, off.
-    fuse_out_ln = os.environ.get("VCT_FUSE_OUT_LN", "0") == "1"
-
     def _attn_ln_fwd(self, b, tag, ntag, lp, np_, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, site_ln, self_attn=True):
-        """y = LayerNorm(x + dropout(out_proj(MHA(x, kv_src)))) of one attention block; saves o, a, mean, rstd for the
-        backward.  Behind the q/k/v projection GEMM(s): attention core, then out_proj + add-LayerNorm as one row-complete launch
-        (ops.linear_ln_fwd) when the shape is covered, else out_proj GEMM + add-LayerNorm kernels; or everything in one launch
-        (fuse_attn_block, off by default)."""
-        d, H = self.cfg["d"], self.cfg["nhead"]
-        Mq = x.shape[0]
-        fuse_all = self.fuse_attn_block and ops.attn_block_supported(self.dt, H, d // H, Lq, Lk)
-        fuse_out = not fuse_all and self.fuse_out_ln and self.dev.type == "cuda" and ops.linear_ln_supported(self.dt, d, d)
-        if not (fuse_all or fuse_out):
-            a = self._attn_block_fwd(b, tag, lp, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn=self_attn)
-            return self._ln_fwd(b, ntag, np_, a, x, site_ln)
-        if self_attn:
-            qkv = b.get(tag + "qkv", (Mq, 3 * d), self.dt)
-            ops.gemm(x, self.W(lp + "in_proj_weight"), qkv, bias=self.F(lp + "in_proj_bias"))
-            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        else:
-            q = b.get(tag + "q", (Mq, d), self.dt)
-            ops.gemm(x, self.W(lp + "in_proj_weight")[:d], q, bias=self.F(lp + "in_proj_bias")[:d])
-            kv = self._cross_kv(b, tag, lp, kv_src)
-            k, v = kv[:, :d], kv[:, d:]
-        o = b.get(tag + "o", (Mq, d), self.dt)
-        a = b.get(tag + "a", (Mq, d), self.dt)
-        y = b.get(ntag + "y", (Mq, d), self.dt)
-        mean, rstd = b.get(ntag + "mean", (Mq,), torch.float32), b.get(ntag + "rstd", (Mq,), torch.float32)
-        drop = self.drop(site)
-        if fuse_out:
-            ops.attn_fwd(q, k, v, o, Bn, H, Lq, Lk, causal=causal, key_pad=key_pad, dropout=drop)
-            return ops.linear_ln_fwd(o, self.W(lp + "out_proj.weight"), self.F(lp + "out_proj.bias"), x, self.F(np_ + "weight"),
-                                     self.F(np_ + "bias"), a, y, mean, rstd, dropout=self.drop(site_ln))
-        return ops.attn_block_fwd(q, k, v, o, Bn, H, Lq, Lk, self.W(lp + "out_proj.weight"), self.F(lp + "out_proj.bias"), x,
-                                  self.F(np_ + "weight"), self.F(np_ + "bias"), a, y, mean, rstd,
-                                  causal=causal, key_pad=key_pad, dropout=drop, site_res=site_ln)
+        """y = LayerNorm(x + dropout(out_proj(MHA(x, kv_src)))) of one attention block; saves o, a, mean, rstd for the backward.
+        (Two fused forms of this block -- attention core + out_proj + add-LayerNorm as one launch, and out_proj + add-LayerNorm as one
+        row-complete launch -- were built in rounds 3/4, measured slower in the step and removed in round 5: git tag
+        archive/r5-off-kernels)"""
+        a = self._attn_block_fwd(b, tag, lp, x, kv_src, Bn, Lq, Lk, causal, key_pad, site, self_attn=self_attn)
+        return self._ln_fwd(b, ntag, np_, a, x, site_ln)
 
     def _cross_kv(self, b, tag, lp, mem):
         """K/V projection of the encoder memory for one cross-attention block.  It depends on the memory only, so
@@ -1450,61 +1391,9 @@ def _decoder_decode_step_fused(self, st: DecodeState, t: int, end_id: int):
     ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
 
 
-def _decoder_bblock_decode_ok(self, st: DecodeState) -> bool:
-    """The batched step with one launch per layer BLOCK (ops.decode_bblock): bf16, d = 512 / 8 heads, ff <= 2048, 2 <= batch <= 256."""
-    d, ff, H = self.cfg["d"], self.cfg["ff"], self.cfg["nhead"]
-    return (self.bblock_decode and 2 <= st.B <= 256 and self.dev.type == "cuda" and st.Lmax <= 64 and st.Te <= 64
-            and ops.decode_bblock_supported(self.dt, d, H, ff, st.B, min(st.Lmax, 64)))
-
-
-def _decoder_decode_step_bblock(self, st: DecodeState, t: int, end_id: int):
-    """The step of _decoder_decode_step for the whole batch in 3 launches per layer + 3: self-attention block, cross-attention block,
-    feed-forward block on 16-row MFMA tiles (each: first product + attention / activation + the second product split over the
-    workgroups that own the first, as partial row blocks), closing norms, generator, selection.  The partials, the residual, the
-    second product's bias and the LayerNorm(s) are folded by the prologue of the next launch (csrc/vct_decode_bblock.hip)."""
-    d, H, L, Bn, Te, Lmax, ff = self.cfg["d"], self.cfg["nhead"], self.cfg["layers"], st.B, st.Te, st.Lmax, self.cfg["ff"]
-    b = st.b
-    f32 = torch.float32
-    xa, x1, x2 = b.get("bx", (Bn, d), f32), b.get("bx1", (Bn, d), f32), b.get("bx2", (Bn, d), f32)
-    a_part, c_part, f_part = b.get("ba", (H, Bn, d), f32), b.get("bc", (H, Bn, d), f32), b.get("bf", (ff // 256, Bn, d), f32)
-    FP = self.ps.want_fragpack
-    prev = None                                   # (bias of linear2, norm3) of the layer below
-    for l in range(L):
-        lp = f"decoder.layers.{l}."
-        sa, ca = lp + "self_attn.", lp + "multihead_attn."
-        cache = st.kv_self[l]                                              # [B * Lmax, 3d]: q | k | v of every consumed token
-        slot = cache[t - 1]                                                # row (t - 1) of sample 0; sample m at + m * Lmax * 3d
-        kw = dict(w_a=FP(self.pre + sa + "in_proj_weight"), b_a=self.F(sa + "in_proj_bias"), a_tile=(0, d // 16, 2 * d // 16), slot=slot,
-                  slot_bs=Lmax * 3 * d, kv=(cache[:, d:2 * d], cache[:, 2 * d:], 3 * d, Lmax * 3 * d), Lk=t,
-                  w_b=FP(self.pre + sa + "out_proj.weight"), part_out=a_part, x_out=xa)
-        if prev is None:      # x = Emb[ys[:, t-1]] + pos[t-1]
-            ops.decode_bblock("self", Bn, embed=(st.ys[:, t - 1], self.F("tgt_to_emb.weight"), self.pos[t - 1]), **kw)
-        else:                 # x = norm3(x2 + linear2 of the layer below)
-            ops.decode_bblock("self", Bn, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1], **kw)
-        kvc = st.kv_cross[l]                                               # [B * Te, 2d]
-        ops.decode_bblock("cross", Bn, res=xa, res_bias=self.F(sa + "out_proj.bias"), part=a_part,
-                          ln1=(self.F(lp + "norm1.weight"), self.F(lp + "norm1.bias")), x_out=x1,
-                          w_a=FP(self.pre + ca + "in_proj_weight"), b_a=self.F(ca + "in_proj_bias")[:d], a_tile=(0, 0, 0),
-                          kv=(kvc[:, :d], kvc[:, d:], 2 * d, Te * 2 * d), Lk=Te, w_b=FP(self.pre + ca + "out_proj.weight"), part_out=c_part)
-        ops.decode_bblock("ffn", Bn, res=x1, res_bias=self.F(ca + "out_proj.bias"), part=c_part,
-                          ln1=(self.F(lp + "norm2.weight"), self.F(lp + "norm2.bias")), x_out=x2,
-                          w_a=FP(self.pre + lp + "linear1.weight"), b_a=self.F(lp + "linear1.bias"), w_b=FP(self.pre + lp + "linear2.weight"),
-                          b_ksteps=ff // 32, part_out=f_part, ff=ff, act=self.cfg["activation"])
-        prev = (self.F(lp + "linear2.bias"), (self.F(lp + "norm3.weight"), self.F(lp + "norm3.bias")))
-    y = b.get("fy", (Bn, d), self.dt)
-    ops.decode_bblock("final", Bn, res=x2, res_bias=prev[0], part=f_part, ln1=prev[1],
-                      ln2=(self.F("decoder.norm.weight"), self.F("decoder.norm.bias")), y_out=y)
-    logits = b.get("logits", (Bn, self.Vp), self.dt)
-    ops.gemm(y, self.W("generator.weight"), logits, bias=self.F("generator.bias"), n_valid=self.V, workspace=self.gemm_ws())
-    st.last_logits = logits          # [B, Vp] of this step (decode.teacher_forced_next_ids reads it)
-    ops.greedy_select(logits, st.ys[:, t], end_id, st.ended, st.ended_count, st.all_ended_at, t, cols=self.V)
-
-
 def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
     if _decoder_block_decode_ok(self, st):
         return _decoder_decode_step_block(self, st, t, end_id)
-    if _decoder_bblock_decode_ok(self, st):
-        return _decoder_decode_step_bblock(self, st, t, end_id)
     if _decoder_small_decode_ok(self, st):
         return _decoder_decode_step_small(self, st, t, end_id)
     if _decoder_fused_decode_ok(self, st):
@@ -1524,14 +1413,6 @@ DecoderEngine.l0_dw_main = int(os.environ.get("VCT_L0_DW_MAIN", "3"))
 DecoderEngine.fused_decode = True             # A/B switch: LayerNorms folded into the skinny projections (2 <= batch <= 256, bf16)
 
 
-# A/B switch: 3 launches per layer at batch 2..256 (bf16, vct_decode_bblock).  Built, tested (teacher-forced against the reference /
-# oracle at batch 16 / 37 / 128), measured SLOWER and therefore off: graph-replayed token step at cfg-B 124.7 / 136.5 / 142.5 / 156.2 us
-# at batch 2 / 16 / 128 / 256 against 98.6 / 104.9 / 116.7 / 151.5 us for the launch-per-projection step (tools/decode_bblock_probe.py,
-# gpurun_out/r4: same box).  A block launch has (heads x row tiles) = 64 workgroups at batch 128, each pulling its head's weights
-# (256 KB), the 8 partial row blocks + residual of the previous block (320 KB fp32) and its rows' cached keys / values through ONE
-# CU's L2 path (~50 B/clk): >= 6 us of operand traffic per launch before any latency, on a quarter of the chip -- the skinny kernels
-# spread the same bytes over 256 workgroups.  (At batch 1 the same design wins because a partial is a 2 KB vector.)
-DecoderEngine.bblock_decode = os.environ.get("VCT_BBLOCK_DECODE", "0") == "1"
 DecoderEngine.block_decode = os.environ.get("VCT_BLOCK_DECODE", "1") != "0"   # A/B switch: 3 launches per layer at batch 1 (bf16)
 DecoderEngine.small_batch_decode = True       # A/B switch: weight-streaming GEMV step for batch <= 4
 DecoderEngine.decode_begin = _decoder_decode_begin

@@ -166,40 +166,7 @@ def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop
     return o
 
 
-_ab_ok = {}
-
-
-def attn_block_supported(dtype, H, hd, Lq, Lk) -> bool:
-    if dtype != torch.bfloat16:
-        return False
-    key = (H, hd, Lq, Lk)
-    r = _ab_ok.get(key)
-    if r is None:
-        r = _ab_ok[key] = bool(L.load().vct_attn_block_supported(L.BF16, H, hd, Lq, Lk))
-    return r
-
-
-def attn_block_fwd(q, k, v, o, B, H, Lq, Lk, w_out, b_out, res, gamma, beta, a_out, y, mean, rstd, causal=False, key_pad=None,
-                   dropout: Drop = None, site_res: int = 0, flags: int = 0):
-    """Fused attention core + out_proj + dropout + residual + LayerNorm (include/vct_hip.h, vct_attn_block_fwd).
-    dropout = (seed, attention-probability site, p); site_res = site of the residual dropout."""
-    hd = o.shape[1] // H
-    bd = L.AttnBlockDesc()
-    a = _attn_desc(q.dtype, B, H, Lq, Lk, hd, causal, q, k, v, key_pad, dropout)
-    a.o, a.ldo = o.data_ptr(), _ld(o)
-    bd.attn = a
-    bd.w_out, bd.ldw, bd.b_out = w_out.data_ptr(), _ld(w_out), b_out.data_ptr()
-    bd.res, bd.ld_res = res.data_ptr(), _ld(res)
-    bd.gamma, bd.beta = gamma.data_ptr(), beta.data_ptr()
-    bd.a_out, bd.ld_a, bd.y, bd.ld_y = a_out.data_ptr(), _ld(a_out), y.data_ptr(), _ld(y)
-    bd.mean, bd.rstd, bd.site_res, bd.reserved = mean.data_ptr(), rstd.data_ptr(), int(site_res), int(flags)
-    L.check(L.load().vct_attn_block_fwd(bd, L.stream_ptr()), "vct_attn_block_fwd")
-    return y
-
-
-# ---- sample-stationary layer forward (csrc/vct_layer_ss.hip) ---------------------------------------------------------------------
 _ss_ok = {}
-SS_CHUNK = 32768          # bf16 elements per 64-KiB chunk of a packed weight stream
 
 
 def layer_ss_supported(dtype, d: int, H: int, ff: int, L_: int, Lm: int) -> bool:
@@ -232,54 +199,6 @@ def ss_pack(blocks, dst: torch.Tensor):
         segs[i].transposed = int(tr)
     L.check(L.load().vct_ss_pack(segs, n, dst.data_ptr(), L.stream_ptr()), "vct_ss_pack")
     return dst
-
-
-def rp_linear_supported(N: int, K: int, epi: int) -> bool:
-    return bool(L.load().vct_rp_linear_supported(L.BF16, int(N), int(K), int(epi)))
-
-
-def rp_pack_transposed(w: torch.Tensor, dst: torch.Tensor = None) -> torch.Tensor:
-    """The stream vct_rp_linear reads for dX = dY W: W = an nn.Linear weight (or a row slice of one) [K = out rows, N = in columns], bf16,
-    as N / 512 transposed blocks of K / 64 chunks each (include/vct_hip.h, vct_rp_linear / vct_ss_pack)."""
-    K, N = w.shape
-    assert N % 512 == 0 and K % 64 == 0 and w.stride(1) == 1 and w.dtype == torch.bfloat16
-    nch = K // 64
-    if dst is None:
-        dst = torch.empty((N // 512) * nch * 32768, dtype=torch.bfloat16, device=w.device)
-    return ss_pack([(w[:, 512 * j:], nch, j * nch, True) for j in range(N // 512)], dst)
-
-
-def rp_linear(dy, wpk, N, *, out=None, addend=None, hpre=None, act="gelu", site=0, seed=None, p_drop=0.0, norm=None):
-    """Row-panel Linear backward (include/vct_hip.h, vct_rp_linear): dX[M, N] = epilogue(dy[M, K] W), W given as the packed transposed
-    stream `wpk` (rp_pack_transposed).  hpre -> epi 1 (activation derivative + dropout mask of the feed-forward), norm = dict(gamma,
-    mean, rstd, ws, xs, res, ds, dxo, site) -> epi 2 (LayerNorm backward), else epi 0.  Replaces ops.gemm(dy, W) (+ ops.add_ln_bwd)."""
-    q = L.RpLinearDesc()
-    M, K = dy.shape
-    epi = 2 if norm is not None else 1 if hpre is not None else 0
-    q.dtype, q.M, q.N, q.K, q.epi, q.act = L.BF16, int(M), int(N), int(K), epi, L.ACT[act]
-    assert dy.dtype == torch.bfloat16 and dy.stride(1) == 1
-    q.A, q.lda, q.wpk = dy.data_ptr(), dy.stride(0), wpk.data_ptr()
-    if out is not None:
-        assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.shape == (M, N)
-        q.out, q.ldo = out.data_ptr(), out.stride(0)
-    if addend is not None:
-        assert addend.dtype == torch.bfloat16 and addend.stride(1) == 1 and addend.shape == (M, N)
-        q.addend, q.ld_addend = addend.data_ptr(), addend.stride(0)
-    if hpre is not None:
-        assert hpre.dtype == torch.bfloat16 and hpre.stride(1) == 1 and hpre.shape == (M, N)
-        q.hpre, q.ld_hpre = hpre.data_ptr(), hpre.stride(0)
-    q.seed, q.site, q.p_drop = L.ptr(seed), int(site), float(p_drop if seed is not None else 0.0)
-    if norm is not None:
-        n = q.norm
-        for k in ("gamma", "mean", "rstd", "ws", "xs", "ds"):
-            setattr(n, k, norm[k].data_ptr())
-        for k in ("xs", "ds", "res", "dxo"):
-            t = norm.get(k)
-            assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous() and t.shape == (M, 512))
-        n.res, n.dxo, n.site = L.ptr(norm.get("res")), L.ptr(norm.get("dxo")), int(norm.get("site", 0))
-        assert norm["ws"].numel() >= ((M + 31) // 32) * 2 * 512 and norm["ws"].dtype == torch.float32
-    L.check(L.load().vct_rp_linear(q, L.stream_ptr()), "vct_rp_linear")
-    return out if norm is None else norm["ds"]
 
 
 def layer_ss_bwd_stream_chunks(ff: int) -> int:
@@ -377,39 +296,6 @@ def layer_ss_fwd(descs):
     """A whole stack (list of layer_ss_desc results, first layer first) in ceil(n / 4) launches (vct_layer_ss_fwd)."""
     arr = (L.LayerSsDesc * len(descs))(*descs)
     L.check(L.load().vct_layer_ss_fwd(arr, len(descs), L.stream_ptr()), "vct_layer_ss_fwd")
-
-
-_ll_ok = {}
-
-
-def linear_ln_supported(dtype, d: int, K: int) -> bool:
-    if dtype != torch.bfloat16:
-        return False
-    r = _ll_ok.get((d, K))
-    if r is None:
-        r = _ll_ok[(d, K)] = bool(L.load().vct_linear_ln_supported(L.BF16, d, K))
-    return r
-
-
-def linear_ln_fwd(x, w, bias, res, gamma, beta, a_out, y, mean, rstd, dropout: Drop = None, ln2=None, rows_per_wg: int = 0):
-    """y = LayerNorm(res + dropout(x w^T + bias)) in one launch (include/vct_hip.h, vct_linear_ln_fwd); a_out receives the bf16
-    pre-dropout product (None: not saved).  ln2 = (gamma2, beta2, y2, mean2, rstd2): also y2 = LayerNorm2(y)."""
-    d = L.LinearLnDesc()
-    d.dtype, d.M, d.d, d.K = L.dtype_code(x.dtype), x.shape[0], w.shape[0], x.shape[1]
-    d.x, d.ldx, d.w, d.ldw, d.bias = x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), bias.data_ptr()
-    if res is not None:
-        d.res, d.ld_res = res.data_ptr(), _ld(res)
-    d.seed, d.site, d.p_drop = _drop(dropout)
-    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
-    if a_out is not None:
-        d.a_out, d.ld_a = a_out.data_ptr(), _ld(a_out)
-    d.y, d.ld_y, d.mean, d.rstd = y.data_ptr(), _ld(y), mean.data_ptr(), rstd.data_ptr()
-    if ln2 is not None:
-        g2, b2, y2, m2, r2 = ln2
-        d.gamma2, d.beta2, d.y2, d.ld_y2, d.mean2, d.rstd2 = g2.data_ptr(), b2.data_ptr(), y2.data_ptr(), _ld(y2), m2.data_ptr(), r2.data_ptr()
-    d.rows_per_wg = rows_per_wg
-    L.check(L.load().vct_linear_ln_fwd(d, L.stream_ptr()), "vct_linear_ln_fwd")
-    return y
 
 
 def attn_bwd(q, k, v, d_o, dq, dk, dv, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop = None):
@@ -683,60 +569,6 @@ def decode_block_supported(dtype, d: int, H: int, ff: int, Lk: int) -> bool:
     if r is None:
         r = _db_ok[key] = bool(L.load().vct_decode_block_supported(L.BF16, d, H, ff, Lk))
     return r
-
-
-_bb_ok = {}
-
-
-def decode_bblock_supported(dtype, d: int, H: int, ff: int, B: int, Lk: int) -> bool:
-    if dtype != torch.bfloat16:
-        return False
-    key = (d, H, ff, B, Lk)
-    r = _bb_ok.get(key)
-    if r is None:
-        r = _bb_ok[key] = bool(L.load().vct_decode_bblock_supported(L.BF16, d, H, ff, B, Lk))
-    return r
-
-
-def pack_frag(w: torch.Tensor, dst: torch.Tensor):
-    """dst <- the bf16 matrix w [N, K] in MFMA-fragment-major order (include/vct_hip.h, vct_pack_frag)."""
-    assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and dst.numel() >= w.numel()
-    L.check(L.load().vct_pack_frag(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], dst.data_ptr(), L.stream_ptr()), "vct_pack_frag")
-    return dst
-
-
-def decode_bblock(kind: str, B: int, *, embed=None, res=None, res_bias=None, part=None, ln1=None, ln2=None, x_out=None, w_a=None, b_a=None,
-                  a_tile=(0, 0, 0), slot=None, slot_bs=0, kv=None, Lk=0, w_b=None, b_ksteps=16, part_out=None, ff=0, act=None, y_out=None):
-    """One block of the batched decode step (include/vct_hip.h, vct_decode_bblock).  kind: 'self' | 'cross' | 'ffn' | 'final'.
-    embed = (ids 1-D view, table, pos_row); part = [n_part, B, 512] fp32 partials of the previous block; kv = (k view, v view, row
-    stride, sample stride); part_out = [n, B, 512] fp32."""
-    q = L.DecodeBBlockDesc()
-    q.kind, q.B, q.ff, q.Lk, q.act, q.b_ksteps = {"self": 0, "cross": 1, "ffn": 2, "final": 3}[kind], int(B), int(ff), int(Lk), L.ACT[act], int(b_ksteps)
-    q.a_tile[0], q.a_tile[1], q.a_tile[2] = (int(t) for t in a_tile)
-    if embed is not None:
-        ids, table, pos_row = embed
-        q.ids, q.id_stride, q.table, q.pos_row = ids.data_ptr(), ids.stride(0), table.data_ptr(), pos_row.data_ptr()
-    if res is not None:
-        q.res, q.ld_res = res.data_ptr(), res.stride(0)
-    q.res_bias = L.ptr(res_bias)
-    if part is not None:
-        q.part, q.part_stride, q.n_part = part.data_ptr(), part.stride(0), part.shape[0]
-    if ln1 is not None:
-        q.g1, q.b1 = ln1[0].data_ptr(), ln1[1].data_ptr()
-    if ln2 is not None:
-        q.g2, q.b2 = ln2[0].data_ptr(), ln2[1].data_ptr()
-    if x_out is not None:
-        q.x_out, q.ld_xout = x_out.data_ptr(), x_out.stride(0)
-    q.w_a, q.b_a, q.w_b = L.ptr(w_a), L.ptr(b_a), L.ptr(w_b)
-    if slot is not None:
-        q.slot, q.slot_bs = slot.data_ptr(), int(slot_bs)
-    if kv is not None:
-        q.kc, q.vc, q.kv_ld, q.kv_bs = kv[0].data_ptr(), kv[1].data_ptr(), int(kv[2]), int(kv[3])
-    if part_out is not None:
-        q.part_out, q.part_out_stride = part_out.data_ptr(), part_out.stride(0)
-    if y_out is not None:
-        q.y_out, q.ld_y = y_out.data_ptr(), y_out.stride(0)
-    L.check(L.load().vct_decode_bblock(q, L.stream_ptr()), "vct_decode_bblock")
 
 
 def transpose(src: torch.Tensor, dst: torch.Tensor):

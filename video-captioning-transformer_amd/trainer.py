@@ -408,6 +408,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg.copy_(fused["exp_avg"])
         self.exp_avg_sq.copy_(fused["exp_avg_sq"])
         self.step_dev.fill_(fused["step"])
+        self._gathered_at = None      # (a restored step count says nothing about the other ranks' shards: gather_state() again before a save)
         self.sync_hyper()
 
 
