@@ -47,7 +47,7 @@ def algorithmic_flops(B, d=512, ff=2048, Le=2, Ld=2, T=T_FRAMES, S=S_TOK, V=VOCA
     dec = B * Sd * (12 * d * d + 4 * d * ff) + 4 * B * Te * d * d + 4 * B * Sd * Sd * d + 4 * B * Sd * Te * d
     gen = 2 * B * Sd * d * V
     fwd = unify + Le * enc + Ld * dec + gen
-    return {"fwd": fwd, "step": 3 * fwd, "gen": gen, "attn_ffn_fwd": Le * enc + Ld * dec}
+    return {"fwd": fwd, "step": 3 * fwd, "gen": gen, "attn_ffn_fwd": Le * enc + Ld * dec, "enc_stack": unify + Le * enc, "dec_stack": Ld * dec}
 
 
 def synthetic(B, rank, device):
@@ -337,19 +337,22 @@ def main():
         torch.cuda.synchronize()
 
     # live kernel timing: HIP events recorded by the C runtime on the launch stream, inside the timed region (they are part
-    # of the recorded launch list, so replays carry them too).  Every bracket is two event records in the stream and all seven
+    # of the recorded launch list, so replays carry them too).  Every bracket is two event records in the stream and all of them
     # cost the step ~55 us (tools/taps_cost.py), so inside the timed region only ONE kernel is bracketed: the roofline kernel =
-    # the LONGEST of the three equal-FLOP generator GEMMs (forward, dX, dW), chosen from the first half of the warm-up, which
-    # runs with every bracket on.  The other brackets (north_star, HBM kernels, ...) come from a short second pass.
+    # the LONGEST single launch of the step among the sample-stationary encoder / decoder stacks, the three generator GEMMs, the loss
+    # and the optimizer's pass, chosen from the first half of the warm-up, which runs with those brackets on.  The other brackets
+    # (north_star, the rest of the top-5, ...) come from a short second pass.
     GEN = ("gen_fwd", "gen_dx", "gen_dw")
+    # candidates for the roofline kernel: every bracket that is ONE launch (or one launch + its fixed-order reduce) of the step
+    CAND = GEN + ("ss_enc", "ss_dec", "loss", "adam")
     dom = "gen_dw"
     w_probe = args.warmup // 2 if args.warmup >= 4 else 0
     if w_probe:
-        ops.taps_enable(True, only=GEN)
+        ops.taps_enable(True, only=CAND)
         for _ in range(w_probe):
             loss = trainer.step(feats, mask, ids)
         sync()
-        probe = {tag: ops.tap_collect(tag) for tag in GEN}
+        probe = {tag: ops.tap_collect(tag) for tag in CAND}
         probe = {k: float(np.mean(v[1:] if len(v) > 1 else v)) for k, v in probe.items() if v}
         if probe:
             dom = max(probe, key=probe.get)
@@ -407,41 +410,69 @@ def main():
     if rank == 0:
         fl = algorithmic_flops(args.batch)
         kern = {k: float(np.mean(v)) for k, v in taps.items() if v}   # ms per bracket, averaged over the timed steps
-        # roofline kernel = the LONGEST of the three equal-FLOP generator GEMMs of the step (picked above, bracketed inside the
-        # timed region).  The weight gradient shares the chip with the encoder backward on the second stream, so its bracket is
-        # co-scheduled time -- that is what the step pays for it, and what is reported.
+        # roofline kernel = the LONGEST single launch of the step (picked above among CAND, bracketed inside the timed region).  The
+        # vocabulary weight gradient shares the chip with the encoder backward on the second stream, so its bracket is co-scheduled
+        # time -- that is what the step pays for it, and what is reported.
         # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/): the entry must name the SAME
         # kernel symbol the tag runs today -- a stale file (the kernel behind a tag changed) yields null, not a wrong number
-        SYMBOL = {"gen_fwd": "gemm256_kernel<0, 1, bf16>", "gen_dx": "gemm256_kernel<0, 1, float>",
-                  "gen_dw": "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"}
-        traffic, traffic_src = None, None
-        for name in ("r04_roofline_traffic.json", "r03_roofline_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                ent = tj[dom]
-                same = ent.get("kernel") is None and name.startswith("r03") or SYMBOL[dom] in str(ent.get("kernel", ""))
-                if args.batch == 256 and args.dtype == "bf16" and same:
-                    traffic, traffic_src = ent["hbm_bytes"], f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of {SYMBOL[dom]}, profiles/{name}"
-                    break
-            except Exception:
-                continue
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        achieved = fl["gen"] / (kern[dom] * 1e-3) / 1e12
-        ms = elapsed / args.steps * 1e3
+        fused_adam = bool(getattr(trainer, "fuse_adam", False))
         Md, Vp = args.batch * (S_TOK - 1), (VOCAB + 31) // 32 * 32
         esz = 2 if args.dtype == "bf16" else 4
         n_par = model.caption_param_end
+        n_adam = getattr(opt, "range_elems", {}).get((0, model.encoder_param_begin), model.encoder_param_begin)
+        # tag -> (bound, algorithmic work per launch [FLOP | bytes], kernel symbol in a rocprofv3 kernel trace, description)
+        INFO = {
+            "gen_fwd": ("mfma", fl["gen"], "gemm256_kernel<0, 1, bf16>",
+                        "generator GEMM fwd 4864x30522x512 (gemm256_kernel NT: persistent 256x256 tiles, 8 waves, LDS-DMA double buffer)"),
+            "gen_dx": ("mfma", fl["gen"], "gemm256_kernel<0, 1, float>" if getattr(model.cap_decoder._engine(), "_wgt", None) is not None
+                       else "gemm256_kernel<0, 0, float>",
+                       "generator dX GEMM 4864x512x30522 (gemm256_kernel, split over K, + fixed-order reduce)"),
+            "gen_dw": ("mfma", fl["gen"], "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>",
+                       "generator dW GEMM 30522x512x4864 (TN, fp32 out" + (", torch.optim.Adam's step on W_g in its epilogue" if fused_adam else "")
+                       + "; runs beside the encoder backward)"),
+            "ss_enc": ("mfma", fl["enc_stack"], "layer_ss_fwd_kernel<false, 1>",
+                       "sample-stationary ENCODER stack forward, one launch: unify Linear + mean token + temporal encoding + 2 layers + final norm"),
+            "ss_dec": ("mfma", fl["dec_stack"], "layer_ss_fwd_kernel<true, 2>",
+                       "sample-stationary DECODER stack forward, one launch: token embedding + 2 layers (self-, cross-attention, feed-forward) + final norm"),
+            "loss": ("hbm", 2 * Md * Vp * esz, "sce_loss_kernel",
+                     "SCE loss + d/dlogits over the materialised logits: one read + one write"),
+            "adam": ("hbm", 30 * n_adam, "adam_ranges_kernel" if fused_adam else "adam_kernel",
+                     "optimizer pass over " + ("what the weight-gradient GEMMs' epilogues did not step (token embedding, biases, LayerNorm parameters)"
+                                                if fused_adam else "everything but the encoder") + ": 16 B read + 14 B written per parameter"),
+        }
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+
+        def roof(tag, ms_):
+            bound, work, _, _ = INFO[tag]
+            if bound == "mfma":
+                ach, pk, unit = work / (ms_ * 1e-3) / 1e12, peak, "TFLOP/s"
+            else:
+                ach, pk, unit = work / (ms_ * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            return bound, ach, pk, unit
+        traffic, traffic_src = None, None
+        for name in ("r05_roofline_traffic.json", "r04_roofline_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                ent = tj[dom]
+                if args.batch == 256 and args.dtype == "bf16" and INFO[dom][2] in str(ent.get("kernel", "")):
+                    traffic, traffic_src = ent["hbm_bytes"], f"rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of {INFO[dom][2]}, profiles/{name}"
+                    break
+            except Exception:
+                continue
+        r_bound, achieved, r_peak, r_unit = roof(dom, kern[dom])
+        ms = elapsed / args.steps * 1e3
+        top5 = sorted(((k, kern[k]) for k in CAND if k in kern), key=lambda kv: -kv[1])[:5]
         hbm = {}
         if "loss" in kern:      # SCE loss + d/dlogits: one read + one write of the logits
             by = 2 * Md * Vp * esz
             hbm["sce_loss"] = {"bytes": by, "ms": round(kern["loss"], 4), "achieved": round(by / (kern["loss"] * 1e-3) / 1e9, 1),
                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / (kern["loss"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
         if "adam" in kern:      # Adam over everything but the encoder: 16 B read + 12 B written (+2 B shadow) per parameter
-            n_adam = model.encoder_param_begin
             by = 30 * n_adam
             hbm["adam"] = {"bytes": by, "ms": round(kern["adam"], 4), "achieved": round(by / (kern["adam"] * 1e-3) / 1e9, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / (kern["adam"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                           "note": f"{n_adam} of {n_par} parameters (the encoder's follow in a second launch)"}
+                           "note": f"{n_adam} of {n_par} parameters in this launch" + (" (weight matrices are stepped inside their weight-gradient GEMMs)"
+                                                                                         if fused_adam else " (the encoder's follow in a second launch)")}
         north = None
         if "layers_fwd" in kern:
             lf = kern["layers_fwd"]
@@ -463,14 +494,13 @@ def main():
                        "executor": "eager" if not (trainer.use_list or trainer.use_graph) else ("list" if trainer.use_list else "graph")},
             "step_tflops": round(fl["step"] / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_peak": round(fl["step"] / (ms * 1e-3) / 1e12 / peak, 4),
-            "roofline": {"bound": "mfma", "kernel_tag": dom,
-                         "kernel": {"gen_fwd": "generator GEMM fwd 4864x30522x512 (gemm256_kernel NT: persistent 256x256 tiles, 8 waves, LDS-DMA double buffer)",
-                                    "gen_dx": "generator dX GEMM 4864x512x30522 (gemm256_kernel NN, split over K, + fixed-order reduce)",
-                                    "gen_dw": "generator dW GEMM 30522x512x4864 (TN, fp32 out; runs beside the encoder backward)"}[dom],
-                         "selection": "longest of gen_fwd / gen_dx / gen_dw (equal FLOPs) in the warm-up probe",
-                         "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "roofline": {"bound": r_bound, "kernel_tag": dom, "kernel": INFO[dom][3], "kernel_symbol": INFO[dom][2],
+                         "selection": "longest single launch of the step among " + " / ".join(CAND) + " in the warm-up probe",
+                         "achieved": round(achieved, 1), "peak": r_peak, "unit": r_unit, "frac": round(achieved / r_peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "flops_per_launch": fl["gen"], "avg_ms_per_launch": round(kern[dom], 4),
+                         ("flops_per_launch" if r_bound == "mfma" else "bytes_per_launch"): INFO[dom][1], "avg_ms_per_launch": round(kern[dom], 4),
+                         "top5": [{"kernel_tag": k, "kernel": INFO[k][2], "bound": roof(k, v)[0], "ms": round(v, 4),
+                                   "frac": round(roof(k, v)[1] / roof(k, v)[2], 4)} for k, v in top5],
                          "generator_gemms": {k: {"ms": round(kern[k], 4), "tflops": round(fl["gen"] / (kern[k] * 1e-3) / 1e12, 1),
                                                  "frac": round(fl["gen"] / (kern[k] * 1e-3) / 1e12 / peak, 4)} for k in GEN if k in kern},
                          "all_ms": {k: round(v, 4) for k, v in kern.items()},

@@ -96,7 +96,7 @@ static int do_wait(int id, hipStream_t st) {
 }
 
 // ---- live timing taps ---------------------------------------------------------------------------------------------
-constexpr int N_TAGS = 16;
+constexpr int N_TAGS = 24;
 struct TapPair { hipEvent_t a, b; };
 static std::vector<TapPair> g_tap_pool[N_TAGS];       // every pair ever created for the tag
 static int g_tap_used[N_TAGS];                        // pairs handed out since the last collect

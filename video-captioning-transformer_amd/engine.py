@@ -746,7 +746,10 @@ class _StackBase:
                 n3=nl, nf=nf, causal=causal, key_pad=kpm, seed=self.seed, p_drop=self.p_drop, sites=sites,
                 frontend=frontend if l == 0 else None, embed=embed if l == 0 else None, **kw))
             y, y2 = nl[2], (nf[2] if nf is not None else None)
+        tag_ = "ss_dec" if cross else "ss_enc"
+        ops.tap(tag_, 0)
         ops.layer_ss_fwd(descs)
+        ops.tap(tag_, 1)
         return y, y2
 
     def _ffn_fwd(self, b, tag, lp, x, site):

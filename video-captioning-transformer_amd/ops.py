@@ -166,7 +166,9 @@ def attn_fwd(q, k, v, o, B, H, Lq, Lk, causal=False, key_pad=None, dropout: Drop
     return o
 
 
+# ---- sample-stationary layer forward (csrc/vct_layer_ss.hip) ---------------------------------------------------------------------
 _ss_ok = {}
+SS_CHUNK = 32768          # bf16 elements per 64-KiB chunk of a packed weight stream
 
 
 def layer_ss_supported(dtype, d: int, H: int, ff: int, L_: int, Lm: int) -> bool:
@@ -689,7 +691,9 @@ def masked_stream(cu_bits, device=None):
 TAPS = {"gen_fwd": 0, "gen_dx": 1, "gen_dw": 2, "layers_fwd": 3, "loss": 4, "adam": 5, "step": 6,
         # data-parallel exchange (trainer.ShardedExchange): what the compute stream WAITS for the communicator at the end of a step,
         # and how long each gradient bucket (reduce-scatter -> Adam on the shard -> all-gather -> cast) occupies the communicator's stream
-        "comm_wait": 7, **{f"comm_b{i}": 8 + i for i in range(8)}}
+        "comm_wait": 7, **{f"comm_b{i}": 8 + i for i in range(8)},
+        # the two sample-stationary stack launches of the forward (encoder incl. its front end / decoder incl. the token embedding)
+        "ss_enc": 16, "ss_dec": 17}
 _taps_on = False
 _taps_only = None        # None = every tag, else the set of tags that are bracketed
 
