@@ -167,7 +167,7 @@ def test_runtime_entry_points_validate_arguments(lib_path):
     assert lib.vct_cmdlist_destroy(h) == 0
     assert lib.vct_sync_record(64, None) == -1 and lib.vct_sync_wait(-1, None) == -1
     assert lib.vct_stream_wait(None, None) == 0              # same stream: no edge needed
-    assert lib.vct_tap(16, 0, None) == -1 and lib.vct_tap(0, 2, None) == -1
+    assert lib.vct_tap(24, 0, None) == -1 and lib.vct_tap(0, 2, None) == -1
     assert lib.vct_tap(0, 0, None) == 0                      # taps disabled: no-op
     assert lib.vct_tap_collect(0, None, 0) == 0
 

@@ -327,7 +327,7 @@ class FusedAdam(torch.optim.Optimizer):
             # the matrices of [a, b) were stepped by their weight-gradient GEMMs (which also wrote their shadows and packed copies): one
             # launch over what is left -- vectors, the embedding table, any matrix whose GEMM did not take the epilogue
             left = self._left_ranges(a, b)
-            self.range_elems[(a, b)] = sum(y - x for x, y in left)        # what this call's launch touches (bench.py: bytes of the bracket)
+            self.range_elems[(a, b)] = sum(r[1] - r[0] for r in left)        # what this call's launch touches (bench.py: bytes of the bracket)
             table, nseg, pk_parts = ps.adam_pack_table(a, b) if (self.pack_in_adam and ps.packed) else (None, 0, [])
             if left:
                 key = (tuple(left), )
