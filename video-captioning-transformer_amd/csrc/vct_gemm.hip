@@ -571,7 +571,8 @@ static long group_tiles(const vct_gemm_desc* descs, int n, const GroupTile& t) {
   return gt;
 }
 static GroupTile grouped_tile(const vct_gemm_desc* descs, int n) {
-  const int sel = descs[0].reserved % 10;
+  static const int env_sel = [] { const char* e = getenv("VCT_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B: 4 / 5 / 8 as below
+  const int sel = descs[0].reserved % 10 ? descs[0].reserved % 10 : env_sel;
   if (sel == 4) return GroupTile{64, 64, 0};
   if (sel == 8) return GroupTile{128, 64, 4};
   if (sel == 5) return GroupTile{128, 128, 1};
@@ -579,7 +580,7 @@ static GroupTile grouped_tile(const vct_gemm_desc* descs, int n) {
   // tiles vs 88 us with 64x64; an encoder layer (192 tiles) 49 us vs 42 us -- one big tile per CU only pays
   // once (nearly) every CU gets one
   const GroupTile big{128, 128, 1};
-  return group_tiles(descs, n, big) >= 224 ? big : GroupTile{64, 64, 0};
+  return group_tiles(descs, n, big) >= 160 ? big : GroupTile{64, 64, 0};      // (in the step, with the group-level XCD map, the 192-tile encoder layer also runs better on 128 x 128: 2.249 vs 2.255 ms, round 5)
 }
 static Plan grouped_plan(const vct_gemm_desc* d, const GroupTile& t, long gt) {
   Plan pl;
