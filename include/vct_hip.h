@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 13
+#define VCT_ABI_VERSION 14
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -375,6 +375,10 @@ int vct_adam_step_2d(float* param, const float* grad, float* exp_avg, float* exp
 /* elementwise helpers ------------------------------------------------------------------------ */
 /* dst[i] = (dst_dtype) src[i], n elements (fp32 <-> bf16 parameter / feature casts) */
 int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* read-only pass over `bytes` bytes at src (16-byte aligned): brings a buffer that the NEXT launch streams (the packed weight streams
+ * of the sample-stationary stacks, whose first touch is otherwise an HBM miss per chunk) into the memory-side cache.  No reference
+ * counterpart (cache placement). */
+int vct_warm(const void* src, int64_t bytes, void* stream);
 /* first-index argmax per row (torch.max(dim=1) tie-break, MMT4Caption.py:165); out[row * out_stride] int64
  * (out_stride lets the decode loop write straight into column t of the id matrix ys[B, max_len]) */
 /* dst[c, r] = src[r, c] (bf16 only): the transposed shadow of the vocabulary projection's weight, so that the input gradient

@@ -713,6 +713,29 @@ extern "C" int vct_sce_loss(int dtype, int N, int S, int V, const void* logits, 
   return VCT_OK;
 }
 
+// read-only pass over a buffer (16 bytes per thread and step): pulls it into the memory-side cache.  The xor of everything read is
+// compared with a value it cannot practically have, so that the loads are not dead code; nothing is ever written.
+namespace vct {
+__global__ __launch_bounds__(256) void warm_kernel(const uint4* __restrict__ src, const int64_t n16, unsigned int* sink) {
+  uint4 a = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w;
+  }
+  if ((a.x ^ a.y) == 0x9e3779b9u && (a.z ^ a.w) == 0x7f4a7c15u && a.x == 0x85ebca6bu && sink != nullptr) *sink = a.w;
+}
+}  // namespace vct
+extern "C" int vct_warm(const void* src, int64_t bytes, void* stream) {
+  if (!src || ((uintptr_t)src & 15)) return VCT_E_ARG;
+  if (bytes < 16) return VCT_E_SHAPE;
+  const int64_t n16 = bytes / 16;
+  const int64_t want = (n16 + 256 * 8 - 1) / (256 * 8);
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  vct::launch(vct::warm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, n16, (unsigned int*)nullptr);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
 extern "C" int vct_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   if (!dt_ok(src_dtype) || !dt_ok(dst_dtype) || !src || !dst) return VCT_E_ARG;
   if (n <= 0) return VCT_E_SHAPE;

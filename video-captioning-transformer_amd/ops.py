@@ -417,6 +417,11 @@ def sce_loss(logits, V, labels, S, pad_id, alpha, loss_out, dlogits, row_ws):
     return loss_out
 
 
+def warm(t: torch.Tensor):
+    """Read-only pass over a tensor: pulls it into the memory-side cache for the launch that streams it next (include/vct_hip.h, vct_warm)."""
+    L.check(L.load().vct_warm(t.data_ptr(), t.numel() * t.element_size(), L.stream_ptr()), "vct_warm")
+
+
 def cast(src, dst):
     L.check(L.load().vct_cast(L.dtype_code(src.dtype), L.dtype_code(dst.dtype), src.data_ptr(), dst.data_ptr(),
                               src.numel(), L.stream_ptr()), "vct_cast")

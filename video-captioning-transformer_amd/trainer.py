@@ -486,6 +486,7 @@ class CaptionTrainer:
 
     # A/B switch (single GPU): the whole Adam pass after the joined backward instead of 86 % of it beside the encoder backward
     adam_after_backward = os.environ.get("VCT_ADAM_TAIL", "0") == "1"
+    warm_streams = os.environ.get("VCT_WARM_STREAMS", "1") != "0"
 
     def _step_kernels(self, feats, mask, ids):
         if not self.fuse_adam:
@@ -560,6 +561,12 @@ class CaptionTrainer:
         else:
             loss = m.train_step_kernels(feats, mask, ids)
             self.opt.step()
+        if self.warm_streams and feats.is_cuda:
+            # the next step begins with the two sample-stationary stack launches, which stream these packed weights chunk by chunk with
+            # two chunks of prefetch: behind the optimizer's passes (1.4 GB of traffic through the memory-side cache) every chunk is an
+            # HBM miss
+            for ent in m._ps.packed.values():
+                ops.warm(ent[0])
         if m.training and m.video_encoder.cfg["dropout"] > 0:
             ops.advance_seed(m._seed)
         ops.tap("step", 1)
