@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """One training step of a rocprofv3 --kernel-trace database as a timeline: for every kernel its queue (stream), start
 offset, duration, and the idle gap since the previous kernel on the same queue.  The step is the window between two
-consecutive adam_kernel groups near the end of the trace.  Dev tool.   python tools/rocpd_timeline.py results.db"""
+consecutive bump_step kernels in the MIDDLE of the trace (argv[2] = fraction of the trace, default 0.45): bench.py's timed steps --
+the last steps of a bench.py trace are its second pass with EVERY timing bracket on, and each bracket (two event records) shows
+up as ~6 us of idle time in front of the kernel behind it (timelines up to round 4 / r5a..r5p were taken there).
+Dev tool.   python tools/rocpd_timeline.py results.db [fraction]"""
 import re
 import sqlite3
 import sys
@@ -19,7 +22,9 @@ def main():
     qcol = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else ("stream_id" if "stream_id" in cols else None))
     rows = c.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
     bumps = [i for i, r in enumerate(rows) if "bump_step" in r[0]]
-    a, b = bumps[-3] + 1, bumps[-2] + 1          # one full step (profiling overhead included)
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.45
+    k = max(1, min(len(bumps) - 2, int(len(bumps) * frac)))
+    a, b = bumps[k - 1] + 1, bumps[k] + 1        # one full step (profiling overhead included)
     step = rows[a:b]
     t0 = step[0][1]
     last_end = {}

@@ -388,7 +388,12 @@ class _StackBase:
     def ensure_side(self):
         ctx = self.ps.ctx
         if ctx.side is None:
-            ctx.side = torch.cuda.Stream(device=self.dev)
+            # a HIGH-priority side stream: in the step's tail it carries the encoder backward's chain of 10-30 us kernels -- the critical
+            # path there -- beside the main stream's 320 us vocabulary weight gradient, whose resident workgroups leave it few slots
+            # (an add_ln_bwd of 10 us took 104 us); with priority the chain wins the slots that do free up: step 2.199 -> 2.187,
+            # 2.216 -> 2.195, 2.254 -> 2.235 ms (same box each; VCT_SIDE_PRIO=0: A/B)
+            prio = -1 if os.environ.get("VCT_SIDE_PRIO", "1") != "0" else 0
+            ctx.side = torch.cuda.Stream(device=self.dev, priority=prio)
             ctx.side_ws = ops.GemmScratch(self.dev)
         return ctx.side
 
@@ -1078,6 +1083,9 @@ class DecoderEngine(_StackBase):
             if early_gen_dw:
                 return
             if defer_gen_dw:
+                # (Measured and dropped, round 5: this product at ONE workgroup per CU -- 40 KB of idle dynamic LDS -- so that the encoder
+                # backward's short kernels on the side stream find free registers beside it: the product went 320 -> 426 us and the
+                # step 2.254 -> 2.289 ms.)
                 ops.gemm(dl, y, self.G("generator.weight"), ta=True, tb=False, bias_grad=self.G("generator.bias"), m_valid=self.V,
                          tag="gen_dw", workspace=self.gemm_ws(), adam=self.dw_adam_desc(dl, self.G("generator.weight")))
             else:
