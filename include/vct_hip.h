@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 14
+#define VCT_ABI_VERSION 15
 
 enum { VCT_F32 = 0, VCT_BF16 = 1 };
 enum { VCT_ACT_NONE = 0, VCT_ACT_GELU = 1, VCT_ACT_RELU = 2 };
@@ -270,6 +270,15 @@ int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const
                    const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
                    float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
                    float p_drop, void* stream);
+/* the backward of vct_add_ln_ln_fwd in one launch: dy2 = gradient of y2 = LayerNorm2(y) (gamma2, mean2, rstd2; y as stored), then
+ * vct_add_ln_bwd of y = LayerNorm(res + dropout(x)) on the gradient of y ROUNDED to the activation type -- bit-identical to the two
+ * vct_add_ln_bwd launches it replaces (the gradient of y is not stored).  param_ws2 / param_ws: one partial-row set per norm
+ * (dgamma / dbeta always deferred to vct_ln_param_finalize_batched).  replaces the autograd nodes of decoder.norm / encoder.norm
+ * (CapDecoder.py:20, MMEncoder.py:238) and of the last layer's closing norm under `loss.backward()` (train.py:125). */
+int vct_add_ln_ln_bwd(int dtype, int M, int d, const void* dy2, const void* y, const float* gamma2, const float* mean2,
+                      const float* rstd2, float* param_ws2, const void* x, const void* res, const float* gamma,
+                      const float* mean, const float* rstd, void* ds, void* dxo, float* param_ws, const uint32_t* seed,
+                      uint32_t site, float p_drop, void* stream);
 int vct_ln_ws_rows(int M);
 /* dgamma == dbeta == NULL in vct_add_ln_bwd defers the column reduction of param_ws; this call then finalizes
  * n_entries LayerNorms in ONE launch.  table_dev: DEVICE int64 [n_entries][4] = {param_ws ptr, dgamma ptr,

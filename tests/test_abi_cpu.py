@@ -38,7 +38,7 @@ def test_binding_covers_header(lib_path):
     from vct_amd import _lib
     assert sorted(set(declared_symbols())) == sorted(set(_lib.exported_symbols()))
     lib = _lib.load()
-    assert lib.vct_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.vct_abi_version() == _lib.ABI_VERSION == 15
     buf = ctypes.create_string_buffer(128)
     assert lib.vct_build_info(buf, 128) > 0 and b"gfx950" in buf.value
 

@@ -46,28 +46,43 @@ def ent(key, name, alg):
             "mfma_busy_cycles": r["SQ_VALU_MFMA_BUSY_CYCLES"], "gui_active_cycles": r["GRBM_GUI_ACTIVE"]}
 
 
-def find(prefix):
-    ks = [k for k in rows if k.startswith(prefix)]
-    return max(ks, key=lambda k: rows[k]["avg_us"] * rows[k]["calls"])
+def find(*prefixes):
+    """The row of the first prefix that occurs (a tag's kernel changes from round to round), the longest-running one of that name."""
+    for prefix in prefixes:
+        ks = [k for k in rows if k.startswith(prefix)]
+        if ks:
+            return max(ks, key=lambda k: rows[k]["avg_us"] * rows[k]["calls"])
+    raise KeyError(prefixes)
+
+
+def opt(name, alg, *prefixes):
+    try:
+        return {name: ent(find(*prefixes), name, alg)}
+    except KeyError:
+        return {}
 
 
 red = rows[find("splitk_reduce_kernel<bf16>")]
-dx = ent(find("gemm256_kernel<0, 1, float>"), "gen_dx", 333000000)
+dx = ent(find("gemm256_kernel<0, 0, float>", "gemm256_kernel<0, 1, float>"), "gen_dx", 333000000)
 dx["reduce_fetch_bytes"], dx["reduce_write_bytes"] = kb(red["FETCH_SIZE"] * 2), kb(red["WRITE_SIZE"])
 dx["hbm_bytes"] += dx["reduce_fetch_bytes"] + dx["reduce_write_bytes"]
-dx["round2"] = old["gen_dx"].get("round2", "")
 ls = rows[find("sce_loss_kernel<bf16")]
-out = {"_source": old["_source"].split("calibrated in the same run")[0] +
+out = {"_source": f"FINAL code of round {int(rnd[1:])}: rocprofv3 --pmc passes of bench.py (tools/pmc_bench.sh -> profiles/{rnd}_pmc_bench_per_kernel.txt), per launch; "
+       "fetch_bytes = FETCH_SIZE [KB] x 1024 x 2 (gfx950: the counter counts 64-byte units as 32), write_bytes = WRITE_SIZE [KB] x 1024; "
        f"calibrated in the same run on sce_loss_kernel: 2 x {ls['FETCH_SIZE']:.4g} KB = {ls['FETCH_SIZE'] * 2 * 1024 / 1e6:.1f} MB fetched / "
        f"{ls['WRITE_SIZE']:.4g} KB = {ls['WRITE_SIZE'] * 1024 / 1e6:.1f} MB written against the 297.0 MB of bf16 logits it reads and the 297.0 MB gradient it writes",
        "gen_fwd": ent(find("gemm256_kernel<0, 1, bf16>"), "gen_fwd", 333000000), "gen_dx": dx,
-       "gen_dw": ent(find("gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 364500000),
-       "sce_loss": ent(find("sce_loss_kernel<bf16"), "sce_loss", 593952768), "adam": ent(find("adam_kernel"), "adam", 0),
-       "adam2d": ent(find("adam2d_kernel"), "adam2d", 0), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048)),
+       # the vocabulary weight gradient WITH the optimizer epilogue: dlogits 297.0 MB + y 5.0 MB read, then per parameter (15,627,264)
+       # p / m / v read and written + the bf16 shadow written = 26 B (no gradient store); without the epilogue it was 364.5 MB
+       "gen_dw": ent(find("gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 297000000 + 5000000 + 26 * 15627264),
+       "sce_loss": ent(find("sce_loss_kernel<bf16"), "sce_loss", 593952768), "adam": ent(find("adam_ranges_kernel", "adam_kernel"), "adam", 0),
+       **opt("adam2d", 0, "adam2d_kernel"), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048)),
        # the sample-stationary stacks: every workgroup streams all of the stack's weights through its XCD's L2 (algorithmic = the
        # weights once + the features / ids read + the tensors saved for the backward)
        "enc_stack_fwd": ent(find("layer_ss_fwd_kernel<false"), "encoder stack forward (2 layers + front end), one launch", 0),
        "dec_stack_fwd": ent(find("layer_ss_fwd_kernel<true"), "decoder stack forward (2 layers + embedding), one launch", 0)}
+# bench.py looks a bracket's traffic up by its tag
+out["loss"], out["ss_enc"], out["ss_dec"] = out["sce_loss"], out["enc_stack_fwd"], out["dec_stack_fwd"]
 json.dump(out, open(P("roofline_traffic.json"), "w"), indent=1)
 d = json.loads(last_json(src + "bench_n1.json"))
 print(f"{d['value']:.0f} samples/s, {d['ms_per_step']} ms/step; roofline {d['roofline']['kernel_tag']} {d['roofline']['frac']}; "

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libvct_hip.so")
 _AB_LIB = os.environ.get("VCT_LIB_PATH")      # developer A/B: load another build of the SAME ABI (tools/ab_build.sh)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 GEMM_GROUP_MAX = 8
 ACT = {"none": 0, None: 0, "gelu": 1, "relu": 2}
 _ERR = {-1: "VCT_E_ARG (null pointer / bad enum)", -2: "VCT_E_SHAPE (unsupported shape)",
@@ -129,6 +129,7 @@ _SIGS = {
     "vct_layer_ss_bwd": (C.c_int, [C.POINTER(LayerSsBwdDesc), C.c_int, vp]),
     "vct_add_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_ln_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
+    "vct_add_ln_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_add_ln_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp]),
     "vct_ln_ws_rows": (C.c_int, [C.c_int]),
     "vct_ln_param_finalize_batched": (C.c_int, [vp, C.c_int, C.c_int, vp]),

@@ -114,12 +114,17 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(int M, int d, const T* 
   }
 }
 
-template <typename T>
+// TWO = true: the backward of a stack-final norm IN FRONT, same launch (the forward's add_ln_ln_fwd): dy is the gradient of
+// y2 = LayerNorm_f(y), y = LayerNorm(res + drop(x)) as stored (fr.x); the gradient of y is rounded to T exactly where the two-launch
+// schedule stores and re-reads it, so the result is bit-identical to vct_add_ln_bwd(final norm) followed by vct_add_ln_bwd(layer norm).
+template <typename T> struct LnFront { const T* x; const float* gamma; const float* mean; const float* rstd; float* ws; };
+
+template <typename T, bool TWO>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          T* __restrict__ ds, T* __restrict__ dxo, float* __restrict__ param_ws,
-                                                         const uint32_t* seed, uint32_t site, float p_drop) {
+                                                         const uint32_t* seed, uint32_t site, float p_drop, const LnFront<T> fr) {
   constexpr int VEC = LnCfg<T>::VEC, MAXIT = LnCfg<T>::MAXIT;
   using RV = RowVec<T, VEC>;
   const int lane = threadIdx.x & 63;
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
   const Dropout dr = make_dropout(seed, site, p_drop);
   const int nvec = d / VEC;
   float pg[MAXIT][VEC], pb[MAXIT][VEC], g[MAXIT][VEC];
+  float pgf[TWO ? MAXIT : 1][VEC], pbf[TWO ? MAXIT : 1][VEC], gf[TWO ? MAXIT : 1][VEC];
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
     const int vi = it * 64 + lane;
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
     for (int j = 0; j < VEC; j++) {
       pg[it][j] = 0.0f; pb[it][j] = 0.0f;
       g[it][j] = (vi < nvec) ? gamma[vi * VEC + j] : 0.0f;
+      if constexpr (TWO) { pgf[it][j] = 0.0f; pbf[it][j] = 0.0f; gf[it][j] = (vi < nvec) ? fr.gamma[vi * VEC + j] : 0.0f; }
     }
   }
   for (int rr = 0; rr < LN_ROWS_PER_WAVE; rr++) {
@@ -141,13 +148,49 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
     if (row >= M) break;
     const float mean = mean_in[row], rstd = rstd_in[row];
     float xh[MAXIT][VEC], dxh[MAXIT][VEC], dm[MAXIT][VEC];
+    float dyin[MAXIT][VEC];                    // the gradient that enters the layer norm (TWO: the front norm's result, rounded to T)
+    if constexpr (TWO) {
+      const float meanf = fr.mean[row], rstdf = fr.rstd[row];
+      float hf[MAXIT][VEC], dhf[MAXIT][VEC];
+      float f1 = 0.0f, f2 = 0.0f;
+#pragma unroll
+      for (int it = 0; it < MAXIT; it++) {
+        const int vi = it * 64 + lane;
+        if (vi < nvec) {
+          const RV xv = *reinterpret_cast<const RV*>(fr.x + (size_t)row * d + vi * VEC);
+          const RV dv = *reinterpret_cast<const RV*>(dy + (size_t)row * d + vi * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const float h = (to_f<T>(xv.v[j]) - meanf) * rstdf;
+            const float dyv = to_f<T>(dv.v[j]);
+            const float dh = dyv * gf[it][j];
+            hf[it][j] = h; dhf[it][j] = dh;
+            f1 += dh; f2 = __fmaf_rn(dh, h, f2);
+            pgf[it][j] = __fmaf_rn(dyv, h, pgf[it][j]); pbf[it][j] += dyv;
+          }
+        }
+      }
+      f1 = wave_sum(f1) / (float)d;
+      f2 = wave_sum(f2) / (float)d;
+#pragma unroll
+      for (int it = 0; it < MAXIT; it++)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          float t = to_f<T>(from_f<T>(__fmul_rn(rstdf, __fsub_rn(__fsub_rn(dhf[it][j], f1), __fmul_rn(hf[it][j], f2)))));
+          // opaque: HIP's __fmul_rn is a plain `*`, and a product feeding `pb += dy` / `dy * g` would otherwise be contracted into
+          // an fma in THIS instantiation only (fp32: the two-launch schedule rounds the product when it stores it)
+          asm volatile("" : "+v"(t));
+          dyin[it][j] = t;
+        }
+    }
     float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
       const int vi = it * 64 + lane;
       if (vi < nvec) {
         const RV xv = *reinterpret_cast<const RV*>(x + (size_t)row * d + vi * VEC);
-        const RV dv = *reinterpret_cast<const RV*>(dy + (size_t)row * d + vi * VEC);
+        RV dv;
+        if constexpr (!TWO) dv = *reinterpret_cast<const RV*>(dy + (size_t)row * d + vi * VEC);
         RV rv;
         if (res != nullptr) rv = *reinterpret_cast<const RV*>(res + (size_t)row * d + vi * VEC);
         float dmv[VEC];
@@ -158,11 +201,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
           float s = to_f<T>(xv.v[j]) * m;
           if (res != nullptr) s += to_f<T>(rv.v[j]);
           const float h = (s - mean) * rstd;
-          const float dyv = to_f<T>(dv.v[j]);
+          float dyv;
+          if constexpr (TWO) dyv = dyin[it][j]; else dyv = to_f<T>(dv.v[j]);
           const float dh = dyv * g[it][j];
           xh[it][j] = h; dxh[it][j] = dh; dm[it][j] = m;
-          c1 += dh; c2 += dh * h;
-          pg[it][j] += dyv * h; pb[it][j] += dyv;
+          c1 += dh; c2 = __fmaf_rn(dh, h, c2);      // (pinned: the one- and two-norm instantiations must contract alike)
+          pg[it][j] = __fmaf_rn(dyv, h, pg[it][j]); pb[it][j] += dyv;
         }
       }
     }
@@ -175,7 +219,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
         RV o1, o2;
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
-          const float v = rstd * (dxh[it][j] - c1 - xh[it][j] * c2);
+          const float v = __fmul_rn(rstd, __fsub_rn(__fsub_rn(dxh[it][j], c1), __fmul_rn(xh[it][j], c2)));
           o1.v[j] = from_f<T>(v);
           o2.v[j] = from_f<T>(v * dm[it][j]);
         }
@@ -188,6 +232,40 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(int M, int d, const T* 
   // partial row per workgroup goes to param_ws[block][0][d] (dgamma) / [block][1][d] (dbeta)
   __shared__ float psum[3][2][1024];
   const int w = threadIdx.x >> 6;
+  auto fold = [&](const float (&a)[TWO ? MAXIT : 1][VEC], const float (&bb)[TWO ? MAXIT : 1][VEC], float* ws, auto N) {
+    constexpr int NIT = decltype(N)::value;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int vi = it * 64 + lane;
+      if (vi < nvec && w > 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          psum[w - 1][0][vi * VEC + j] = a[it][j];
+          psum[w - 1][1][vi * VEC + j] = bb[it][j];
+        }
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int vi = it * 64 + lane;
+        if (vi < nvec) {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const int c = vi * VEC + j;
+            ws[((size_t)blockIdx.x * 2 + 0) * d + c] = a[it][j] + psum[0][0][c] + psum[1][0][c] + psum[2][0][c];
+            ws[((size_t)blockIdx.x * 2 + 1) * d + c] = bb[it][j] + psum[0][1][c] + psum[1][1][c] + psum[2][1][c];
+          }
+        }
+      }
+    }
+  };
+  if constexpr (TWO) {
+    fold(pgf, pbf, fr.ws, std::integral_constant<int, MAXIT>{});
+    __syncthreads();
+  }
+  // (the layer norm's own partials: same code on arrays of MAXIT rows)
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
     const int vi = it * 64 + lane;
@@ -324,29 +402,55 @@ extern "C" int vct_add_ln_ln_fwd(int dtype, int M, int d, const void* x, const v
   return add_ln_fwd_launch(dtype, M, d, x, res, gamma, beta, y, mean, rstd, seed, site, p_drop, n2, true, (hipStream_t)stream);
 }
 
-extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,
-                              const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
-                              float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
-                              float p_drop, void* stream) {
+static int add_ln_bwd_launch(int dtype, int M, int d, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                             const float* rstd, void* ds, void* dxo, float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed,
+                             uint32_t site, float p_drop, const void* xf, const float* gammaf, const float* meanf, const float* rstdf,
+                             float* wsf, void* stream) {
   int rc = ln_check(dtype, M, d);
   if (rc) return rc;
   if (!dy || !x || !gamma || !mean || !rstd || !ds || !param_ws) return VCT_E_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return VCT_E_ARG;
+  const bool two = xf != nullptr;
+  if (two && (!gammaf || !meanf || !rstdf || !wsf || dgamma != nullptr)) return VCT_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nws = vct_ln_ws_rows(M);
   const dim3 grid(nws);
-  if (dtype == VCT_BF16)
-    vct::launch((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop);
-  else
-    vct::launch((add_ln_bwd_kernel<float>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
-                       (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop);
+  if (dtype == VCT_BF16) {
+    const LnFront<bf16_t> fr{(const bf16_t*)xf, gammaf, meanf, rstdf, wsf};
+    if (two) vct::launch((add_ln_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
+                         (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop, fr);
+    else vct::launch((add_ln_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, st, M, d, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)ds, (bf16_t*)dxo, param_ws, seed, site, p_drop, fr);
+  } else {
+    const LnFront<float> fr{(const float*)xf, gammaf, meanf, rstdf, wsf};
+    if (two) vct::launch((add_ln_bwd_kernel<float, true>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
+                         (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop, fr);
+    else vct::launch((add_ln_bwd_kernel<float, false>), grid, dim3(256), 0, st, M, d, (const float*)dy, (const float*)x,
+                     (const float*)res, gamma, mean, rstd, (float*)ds, (float*)dxo, param_ws, seed, site, p_drop, fr);
+  }
   VCT_CHECK_LAUNCH();
   if (dgamma != nullptr && dbeta != nullptr) {   // NULL: the caller finalizes later with vct_ln_param_finalize_batched
     vct::launch(ln_param_finalize_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st, nws, d, param_ws, dgamma, dbeta);
     VCT_CHECK_LAUNCH();
   }
   return VCT_OK;
+}
+
+extern "C" int vct_add_ln_bwd(int dtype, int M, int d, const void* dy, const void* x, const void* res,
+                              const float* gamma, const float* mean, const float* rstd, void* ds, void* dxo,
+                              float* dgamma, float* dbeta, float* param_ws, const uint32_t* seed, uint32_t site,
+                              float p_drop, void* stream) {
+  return add_ln_bwd_launch(dtype, M, d, dy, x, res, gamma, mean, rstd, ds, dxo, dgamma, dbeta, param_ws, seed, site, p_drop, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int vct_add_ln_ln_bwd(int dtype, int M, int d, const void* dy2, const void* y, const float* gamma2, const float* mean2,
+                                 const float* rstd2, float* param_ws2, const void* x, const void* res, const float* gamma,
+                                 const float* mean, const float* rstd, void* ds, void* dxo, float* param_ws, const uint32_t* seed,
+                                 uint32_t site, float p_drop, void* stream) {
+  if (!y) return VCT_E_ARG;
+  return add_ln_bwd_launch(dtype, M, d, dy2, x, res, gamma, mean, rstd, ds, dxo, nullptr, nullptr, param_ws, seed, site, p_drop, y, gamma2,
+                           mean2, rstd2, param_ws2, stream);
 }
 
 extern "C" int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream) {

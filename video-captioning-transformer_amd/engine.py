@@ -581,6 +581,24 @@ class _StackBase:
                                  ops.ln_ws_rows(M)))
         return ds, dxo
 
+    fuse_ln_ln_bwd = os.environ.get("VCT_LN_LN_BWD", "1") != "0"      # A/B switch
+
+    def _ln_ln_bwd(self, b, tag2, np2, dy2, y, tag, np_, x, res, site):
+        """The stack-final norm's backward and the top layer's closing norm's backward in ONE launch (ops.add_ln_ln_bwd; bit-identical
+        to _ln_bwd(final) followed by _ln_bwd(layer)).  Returns (ds, dxo) of the layer norm."""
+        M, d = x.shape
+        ds = b.get(tag + "ds", (M, d), self.dt)
+        drop = self.drop(site) if site is not None else None
+        dxo = b.get(tag + "dxo", (M, d), self.dt) if drop is not None else ds
+        rows = ops.ln_ws_rows(M)
+        ws2 = b.get(tag2 + "ln_ws", (2 * rows * d,), torch.float32)
+        ws = b.get(tag + "ln_ws", (2 * rows * d,), torch.float32)
+        ops.add_ln_ln_bwd(dy2, y, self.F(np2 + "weight"), b.t[tag2 + "mean"], b.t[tag2 + "rstd"], ws2, x, res, self.F(np_ + "weight"),
+                          b.t[tag + "mean"], b.t[tag + "rstd"], ds, dxo, ws, dropout=drop)
+        for w_, n_ in ((ws2, np2), (ws, np_)):
+            self._ln_pending.append((w_.data_ptr(), self.G(n_ + "weight").data_ptr(), self.G(n_ + "bias").data_ptr(), rows))
+        return ds, dxo
+
     def flush_ln_grads(self, b):
         """One launch: dgamma/dbeta of every LayerNorm whose backward ran since the last flush."""
         if not self._ln_pending:
@@ -893,11 +911,16 @@ class EncoderEngine(_StackBase):
             if bucket_ready is not None:
                 bucket_ready("enc_layer", 0)
             return
-        dx, _ = self._ln_bwd(b, "nf.", "transformer_encoder.norm.", dmem, b.t["x_last"], None, None)
+        if not self.fuse_ln_ln_bwd:
+            dx, _ = self._ln_bwd(b, "nf.", "transformer_encoder.norm.", dmem, b.t["x_last"], None, None)
         for l in reversed(range(L)):
             lp, tag, site = f"transformer_encoder.layers.{l}.", f"L{l}.", ENC_SITE + 16 * l
             x, x1 = b.t[tag + "x"], b.t[tag + "n1.y"]
-            ds2, df = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx, b.t[tag + "ff.f"], x1, site + 4)
+            if l == L - 1 and self.fuse_ln_ln_bwd:      # stack-final norm + this layer's norm2: one launch
+                ds2, df = self._ln_ln_bwd(b, "nf.", "transformer_encoder.norm.", dmem, b.t["x_last"], tag + "n2.", lp + "norm2.",
+                                          b.t[tag + "ff.f"], x1, site + 4)
+            else:
+                ds2, df = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx, b.t[tag + "ff.f"], x1, site + 4)
             dx1 = self._ffn_bwd(b, tag + "ff.", lp, df, x1, site + 3, ds2)
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
@@ -1094,12 +1117,17 @@ class DecoderEngine(_StackBase):
             gen_dw()
         if bucket_ready is not None:
             self.bucket_on_side(bucket_ready, "generator")
-        dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
+        if not self.fuse_ln_ln_bwd:
+            dx, _ = self._ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], None, None)
         dmem = b.get("dmem", (Bn * Te, d), self.dt)
         for l in reversed(range(L)):
             lp, tag, site = f"decoder.layers.{l}.", f"L{l}.", DEC_SITE + 16 * l
             x, x1, x2 = b.t[tag + "x"], b.t[tag + "n1.y"], b.t[tag + "n2.y"]
-            ds3, df = self._ln_bwd(b, tag + "n3.", lp + "norm3.", dx, b.t[tag + "ff.f"], x2, site + 6)
+            if l == L - 1 and self.fuse_ln_ln_bwd:      # stack-final norm + this layer's norm3: one launch
+                ds3, df = self._ln_ln_bwd(b, "nf.", "decoder.norm.", dy, b.t["x_last"], tag + "n3.", lp + "norm3.", b.t[tag + "ff.f"], x2,
+                                          site + 6)
+            else:
+                ds3, df = self._ln_bwd(b, tag + "n3.", lp + "norm3.", dx, b.t[tag + "ff.f"], x2, site + 6)
             dx2 = self._ffn_bwd(b, tag + "ff.", lp, df, x2, site + 5, ds3)
             ds2, dc = self._ln_bwd(b, tag + "n2.", lp + "norm2.", dx2, b.t[tag + "ca.a"], x1, site + 4)
             dx1 = self._attn_block_bwd(b, tag + "ca.", lp + "multihead_attn.", dc, x1, mem, Bn, Sd, Te, False, None, site + 3,

@@ -341,6 +341,16 @@ def add_ln_bwd(dy, x, res, gamma, mean, rstd, ds, dxo, dgamma, dbeta, param_ws, 
                                     L.stream_ptr()), "vct_add_ln_bwd")
 
 
+def add_ln_ln_bwd(dy2, y, gamma2, mean2, rstd2, param_ws2, x, res, gamma, mean, rstd, ds, dxo, param_ws, dropout: Drop = None):
+    """Backward of add_ln_ln_fwd in one launch (include/vct_hip.h, vct_add_ln_ln_bwd): the stack-final norm, then the last layer's norm."""
+    M, dm = x.shape
+    s, site, p = _drop(dropout)
+    L.check(L.load().vct_add_ln_ln_bwd(L.dtype_code(x.dtype), M, dm, dy2.data_ptr(), y.data_ptr(), gamma2.data_ptr(), mean2.data_ptr(),
+                                       rstd2.data_ptr(), param_ws2.data_ptr(), x.data_ptr(), L.ptr(res), gamma.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), ds.data_ptr(), L.ptr(dxo), param_ws.data_ptr(), s, site, p, L.stream_ptr()),
+            "vct_add_ln_ln_bwd")
+
+
 def ln_param_finalize_batched(table, n_entries, d):
     """table: int64 device tensor [n_entries, 4] = (param_ws ptr, dgamma ptr, dbeta ptr, ws rows)."""
     L.check(L.load().vct_ln_param_finalize_batched(table.data_ptr(), n_entries, d, L.stream_ptr()), "vct_ln_param_finalize_batched")
