@@ -8,7 +8,7 @@
 
 namespace vct {
 
-constexpr int LN_ROWS_PER_WAVE = 2;   // 8 rows per 4-wave workgroup: enough workgroups to fill 256 CUs at M ~ 5k
+constexpr int LN_ROWS_PER_WAVE = 1;   // 4 rows per 4-wave workgroup (round 5, in the step: 2.172 -> 2.164 ms against 2 rows per wave, 2.176 with 4)
 
 template <typename T> struct LnCfg;
 template <> struct LnCfg<float> { static constexpr int VEC = 4, MAXIT = 4; };
