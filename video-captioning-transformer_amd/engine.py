@@ -388,12 +388,12 @@ class _StackBase:
     def ensure_side(self):
         ctx = self.ps.ctx
         if ctx.side is None:
-            # a HIGH-priority side stream: in the step's tail it carries the encoder backward's chain of 10-30 us kernels -- the critical
-            # path there -- beside the main stream's 320 us vocabulary weight gradient, whose resident workgroups leave it few slots
-            # (an add_ln_bwd of 10 us took 104 us); with priority the chain wins the slots that do free up: step 2.199 -> 2.187,
-            # 2.216 -> 2.195, 2.254 -> 2.235 ms (same box each; VCT_SIDE_PRIO=0: A/B)
-            prio = -1 if os.environ.get("VCT_SIDE_PRIO", "1") != "0" else 0
-            ctx.side = torch.cuda.Stream(device=self.dev, priority=prio)
+            # Normal priority.  (Round 5 measured a HIGH-priority side stream: without a gradient exchange the encoder backward's short
+            # kernels win freed slots beside the vocabulary weight gradient -- step -0.8 % in three same-box pairs, 0 in a fourth, i.e.
+            # inside the run-to-run spread -- but WITH an exchange, collectives in flight on the communicator's stream, every kernel of
+            # the step is stretched: world size 1, sharded exchange, 2.88 -> 4.69 ms.  Not worth a stream whose effect depends on what
+            # else is in flight: dropped.)
+            ctx.side = torch.cuda.Stream(device=self.dev)
             ctx.side_ws = ops.GemmScratch(self.dev)
         return ctx.side
 
