@@ -69,6 +69,8 @@ def test_new_entry_points_validate_arguments(lib_path):
     assert lib.vct_gemm_grouped_workspace_bytes(arr, 2, 5) == 0
     assert lib.vct_greedy_select(1, 4, 10, None, 16, None, 1, 102, None, None, None, 3, None) == -1
     assert lib.vct_gather_pad_rows(0, 4, 3, 16, None, None, None, None, None, None) == -1
+    assert lib.vct_warm(None, 64, None) == -1 and lib.vct_warm(ctypes.c_void_p(16), 8, None) == -2
+    assert lib.vct_add_ln_ln_bwd(1, 8, 64, *([None] * 15), 0, 0.0, None) == -1
 
 
 def test_descriptor_structs_match_the_c_header(tmp_path):
