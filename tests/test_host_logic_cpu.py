@@ -137,3 +137,26 @@ def test_torch_like_initialisation_statistics():
     assert float(sd["cap_decoder.decoder.layers.0.self_attn.in_proj_bias"].abs().sum()) == 0.0
     assert abs(float(sd["cap_decoder.tgt_to_emb.weight"][1:].std()) - 1.0) < 0.02
     assert torch.equal(sd["cap_decoder.decoder.layers.0.linear1.weight"], sd["cap_decoder.decoder.layers.2.linear1.weight"])
+
+
+def test_optimizer_ranges_left_by_the_weight_gradient_epilogues():
+    """Host logic of the single-GPU schedule (trainer.FusedAdam): what the weight-gradient GEMMs' optimizer epilogues step is cut
+    out of a flat range, the rest is split at the shadow-less token-embedding table, and the multi-range launch's table numbers its
+    4096-element workgroups range after range (include/vct_hip.h, vct_adam_range)."""
+    import ctypes
+    from vct_amd import _lib, ops
+    from vct_amd.trainer import FusedAdam
+    opt = FusedAdam.__new__(FusedAdam)
+    opt.skip = (10000, 20000)                                   # the embedding table: no bf16 shadow
+    opt._dw_ranges = [(4096, 8192), (0, 1024), (30000, 40960), (4096, 8192)]     # registered twice: harmless
+    left = opt._left_ranges(0, 50000)
+    assert left == [(1024, 4096, True), (8192, 10000, True), (10000, 20000, False), (20000, 30000, True), (40960, 50000, True)]
+    assert opt._left_ranges(4096, 8192) == [] and opt._left_ranges(9000, 21000) == [(9000, 10000, True), (10000, 20000, False), (20000, 21000, True)]
+    table, n, blocks = ops.adam_ranges_table(left, "cpu")
+    assert n == 5 and table.numel() == n * ctypes.sizeof(_lib.AdamRange)
+    arr = (_lib.AdamRange * n).from_buffer_copy(bytes(table.numpy().tobytes()))
+    want_blk, at = [], 0
+    for a, b, _sh in left:
+        want_blk.append(at); at += (b - a + 4095) // 4096
+    assert [r.blk0 for r in arr] == want_blk and blocks == at
+    assert [(r.begin, r.end, r.shadow) for r in arr] == [(a, b, int(sh)) for a, b, sh in left]
