@@ -221,6 +221,47 @@ def test_packed_stream_follows_the_weights():
     assert rel(out[True][1], out[False][1]) < 2e-2
 
 
+def test_packed_stream_created_after_a_recording_is_kept_current():
+    """ADVICE (round 4): a packed stream that comes into being AFTER another shape's launch list was recorded must not go stale.  A
+    caption shape the sample-stationary decoder rejects (34 decoder rows > 32) is recorded first -- no decoder stream exists yet -- then an
+    eligible shape creates the stream and records its own list; the shapes then alternate.  Every replay of either list must leave every
+    packed stream equal to a fresh vct_ss_pack of the current shadow, bit for bit, and the eligible shape's losses must be those of the
+    unfused schedule run on the same sequence."""
+    from vct_amd import ops
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    V, B, T = 500, 4, 9
+    mc = _mc(enc=1, dec=1, ff=512, dropout=0.0)
+    cfg = O.cfg_from_model_config(mc, V)
+    p = O.init_params(cfg, seed=12)
+    long_b = tuple(torch.from_numpy(a).to(DEV) for a in O.synthetic_batch(B, T, 512, 35, V, seed=40))      # 34 decoder rows: unfused decoder
+    short_b = [tuple(torch.from_numpy(a).to(DEV) for a in O.synthetic_batch(B, T, 512, 11, V, seed=41 + k)) for k in range(3)]
+    seq = [long_b, short_b[0], long_b, short_b[1], long_b, short_b[2]]
+    out = {}
+    old = _fuse(True)
+    try:
+        for fused in (True, False):
+            _fuse(fused)
+            m = build_model(mc, V, DEV, BF, p)
+            m.train()
+            tr = CaptionTrainer(m, FusedAdam(m, lr=3e-3), launch_list=True)
+            losses = []
+            for k, (fe, mk, ii) in enumerate(seq):
+                losses.append(float(tr.step(fe, mk, ii)))
+                if fused:
+                    torch.cuda.synchronize()
+                    if k >= 1:
+                        assert any("decoder" in key for key in m._ps.packed), list(m._ps.packed)
+                    for key, (stream, _firsts, subs) in m._ps.packed.items():
+                        fresh = ops.ss_pack([blk for sub in subs for blk in sub[2]], stream.clone())
+                        torch.cuda.synchronize()
+                        assert torch.equal(fresh.view(torch.int16), stream.view(torch.int16)), (k, key)
+            out[fused] = losses
+    finally:
+        _fuse(old)
+    for a, b in zip(out[True], out[False]):
+        assert abs(a - b) < 3e-3 * abs(b), (out[True], out[False])
+
+
 def test_fused_step_is_bitwise_deterministic_with_dropout():
     from vct_amd.trainer import CaptionTrainer, FusedAdam
     V = 900
