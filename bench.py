@@ -120,6 +120,30 @@ def cpu_baseline():
                       f"(T=12->S=20, V=30522); " + "; ".join(legs) + f"; {spent:.1f} s of timed CPU work", "loss": loss}
 
 
+def exchange_path_n1(batch, dtype):
+    """The schedule every N > 1 run takes -- reduce-scatter -> Adam on the owned shard -> all-gather per gradient bucket on the
+    communicator's stream (`sharded`), or bucketed all-reduce + per-bucket Adam (`allreduce`) -- at world size 1, where the
+    collectives move no bytes: what a rank pays for the exchange path BEFORE any wire time (no optimizer epilogue in the
+    weight-gradient GEMMs there).  Untimed side line: each leg is this script in its own process (own RCCL communicator),
+    --force-exchange, 4 warm-up + 10 timed steps."""
+    import subprocess
+    out = {"what": "bench.py --force-exchange at world size 1 (own process per leg, 4 warm-up + 10 timed steps)"}
+    for kind in ("sharded", "allreduce"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "4", "--batch", str(batch),
+               "--dtype", dtype, "--force-exchange", "--exchange", kind, "--no-cpu-baseline", "--no-decode", "--no-b1024",
+               "--no-other-configs", "--no-exchange-line"]
+        env = dict(os.environ, MASTER_PORT=str(29531 + (kind == "allreduce")))
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            out[kind + "_ms"] = line["ms_per_step"]
+            out[kind + "_comm"] = (line.get("comm") or {}).get("kind")
+        except Exception as e:
+            out[kind + "_ms"] = None
+            out[kind + "_error"] = repr(e)[:200]
+    return out
+
+
 OTHER_CONFIGS = (("shipped d=768 1+3 T=12 S=20", 768, 1, 3, 12, 20), ("configs[3] d=1024 6+6 T=32 S=40", 1024, 6, 6, 32, 40))
 
 
@@ -233,6 +257,7 @@ def main():
     ap.add_argument("--no-overlap-enc", action="store_true", help="A/B: encoder backward after (not beside) the decoder's tail")
     ap.add_argument("--no-group-dw", action="store_true", help="A/B: one launch per weight-gradient GEMM instead of one per layer")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL gradient exchange even at world size 1 (plumbing test)")
+    ap.add_argument("--no-exchange-line", action="store_true", help="skip the exchange_path_n1 side line (the N > 1 schedule at world size 1)")
     ap.add_argument("--torch-adam", action="store_true", help="A/B: torch.optim.Adam(fused=True) + cast kernels instead of vct_adam_step")
     args = ap.parse_args()
 
@@ -528,6 +553,8 @@ def main():
             out["other_configs"] = other_configs(device, model.compute_dtype, peak)
         if world == 1 and not args.no_decode:
             out["decode"] = decode_line(device, model.compute_dtype)
+        if world == 1 and not args.no_exchange_line and not args.force_exchange and args.batch == 256:
+            out["exchange_path_n1"] = exchange_path_n1(args.batch, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         json_out.write(json.dumps(out) + "\n")

@@ -44,6 +44,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    # objects (and their stamps) of sources that are no longer part of the library: unlinked, but build/ ships to the GPU box
+    keep = {s.replace(".hip", ".o") for s in srcs}
+    for fn in os.listdir(os.path.join(PKG, "build")):
+        base = fn[:-len(".stamp")] if fn.endswith(".stamp") else fn
+        if base.endswith(".o") and base not in keep:
+            os.remove(os.path.join(PKG, "build", fn))
 
     # per-object stamps: a source is recompiled when it, any header, or the flags changed (editing one .hip rebuilds one object)
     hh = hashlib.sha256(" ".join(FLAGS).encode())

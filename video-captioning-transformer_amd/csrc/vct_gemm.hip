@@ -434,6 +434,9 @@ static int check_desc(const vct_gemm_desc* d) {
     if (a->pk_stream != nullptr && (a->shadow == nullptr || ((uintptr_t)a->pk_stream & 15) || a->pk_K < d->N || (a->pk_K % 8) ||
                                     a->pk_row0 < 0 || (a->pk_mode != 0 && a->pk_mode != 1)))
       return VCT_E_ARG;
+    // the kernel carries the first chunk of each block as a 16-bit field, 0xffff = "not packed": a larger index cannot be expressed
+    if (a->pk_stream != nullptr)
+      for (int i = 0; i < 4; i++) if (a->pk_chunk0[i] >= 0xffff) return VCT_E_ARG;
   }
   return VCT_OK;
 }

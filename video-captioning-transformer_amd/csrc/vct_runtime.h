@@ -5,6 +5,7 @@
 // edges are recorded event record / wait pairs).  See vct_runtime.hip and include/vct_hip.h (vct_cmdlist_*).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <functional>
 
 namespace vct {
@@ -28,14 +29,14 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: a process that drives several GPUs must opt in on each of them (a
 // once-per-process flag left the > 64 KB launches of the second device failing).  One bit per device per call site.
 struct DynLdsOptIn {
-  unsigned long long done[4] = {0, 0, 0, 0};      // up to 256 devices
+  std::atomic<unsigned long long> done[4] = {};   // up to 256 devices; host threads driving different devices may race here
   hipError_t ensure(const void* fn, int bytes) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 256 && ((done[dev >> 6] >> (dev & 63)) & 1ull)) return hipSuccess;
+    if (dev >= 0 && dev < 256 && ((done[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
+    if (e == hipSuccess && dev >= 0 && dev < 256) done[dev >> 6].fetch_or(1ull << (dev & 63), std::memory_order_release);
     return e;
   }
 };

@@ -92,6 +92,9 @@ class ParamSet:
         # the optimizer that steps weight matrices INSIDE their weight-gradient GEMMs (trainer.FusedAdam.enable_dw_fusion; None: nobody
         # does): _StackBase.dw_gemm asks it for the epilogue descriptor of every gradient view it is about to produce
         self.dw_adam = None
+        # False after a step whose weight-gradient GEMMs consumed their gradients in registers (optimizer epilogue, store_grad = 0): the
+        # 2-D weights' regions of gflat (and their .grad views) then hold values of an EARLIER backward.  MMT4Caption.grads_valid.
+        self.weight_grads_valid = True
         self._starts = None
         # contiguous [start, end) ranges to cast (everything except the no_shadow tensors)
         self.cast_ranges, start = [], 0
@@ -230,9 +233,19 @@ class ParamSet:
         starts = sorted((off, n) for n, off in self.offsets.items())
         segs, parts = {}, []
         c0 = self.cflat.data_ptr()
+        # ONE choice of stream per weight for the whole parameter set: the table of a sub-range is the whole-buffer selection
+        # filtered to [a, b) -- the GEMM epilogues take their packed-stream targets from the (0, total) table (pack_seg) and step_range
+        # marks parts as written from the (a, b) one; built independently the two could settle on different streams for a weight
+        # that two eligible streams hold, and the one nobody writes would go stale
+        full = None
+        if (a, b) != (0, self.total):
+            self.adam_pack_table(0, self.total)
+            full = set(id(x) for x in self._adam_pack[(0, self.total, key[2])][2])
         for ent in self.packed.values():
             for sub in ent[2]:
                 if not (a <= sub[0] and sub[1] <= b):
+                    continue
+                if full is not None and id(sub) not in full:
                     continue
                 ok, mine = True, {}
                 for blk in sub[2]:
@@ -256,6 +269,9 @@ class ParamSet:
                     else:
                         ok = False
                         break
+                    if dc >= 0xffff:
+                        ok = False            # the kernels carry the first chunk of a block as a 16-bit field (0xffff = "not packed"): a
+                        break                 # stream of >= 4 GiB stays with vct_ss_pack instead of silently going stale
                     if name in segs and segs[name][5] != ent[0].data_ptr():
                         ok = False            # another stream already holds this weight: the kernel's table has ONE stream per weight,
                         break                 # so this part stays with vct_ss_pack (refresh_transposed) instead of going stale

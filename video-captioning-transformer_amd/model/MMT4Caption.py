@@ -109,6 +109,21 @@ class MMT4Caption(nn.Module):
     def flat_grads(self) -> torch.Tensor:
         return self._ps.gflat
 
+    @property
+    def grads_valid(self) -> bool:
+        """True when every `.grad` / `flat_grads` element is the gradient of the LAST backward, as after the reference's
+        `loss.backward()` (train.py:125).  False after a CaptionTrainer step that stepped the weight matrices inside their
+        weight-gradient GEMMs without storing the gradients (single GPU, bf16, FusedAdam -- the default there): bias, LayerNorm and
+        embedding gradients are current, the 2-D weights' are stale.  `CaptionTrainer(..., keep_weight_grads=True)` keeps all valid."""
+        return self._ps.weight_grads_valid
+
+    def check_grads_valid(self):
+        """Raise if the weight-matrix gradients are stale (call before gradient clipping / logging / hooks that read .grad)."""
+        if not self._ps.weight_grads_valid:
+            raise RuntimeError("the last CaptionTrainer.step() stepped the weight matrices inside their weight-gradient GEMMs and did not "
+                               "store those gradients: .grad / flat_grads of 2-D weights are stale; construct the trainer with "
+                               "keep_weight_grads=True (or set VCT_FUSE_ADAM_KEEP_GRAD=1) to keep them")
+
     def grad_buckets(self):
         """Contiguous [start, end) element ranges of the flat gradient buffer in the order the backward
         pass completes them: generator | decoder norm + top layer | ... | decoder layer 0 | token embedding |
@@ -218,6 +233,8 @@ class MMT4Caption(nn.Module):
         gradient buffer, whose views are installed as `.grad`.  Returns the loss tensor [1]."""
         loss, _ = self._forward_loss(feats, mask, ids, self.training)
         self._backward(bucket_ready, join=not defer_join)     # defer_join: the caller calls join_backward() itself
+        opt = self._ps.dw_adam                                # the optimizer epilogue consumed the weight gradients unless told to store them
+        self._ps.weight_grads_valid = opt is None or bool(opt.keep_grads)
         return loss
 
     # ---- reference API -----------------------------------------------------------------------------

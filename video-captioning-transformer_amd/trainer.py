@@ -252,6 +252,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._dw_ranges = []
         return ok
 
+    def set_keep_grads(self, on: bool):
+        """Store the weight gradients from the optimizer epilogues as well (CaptionTrainer(keep_weight_grads=...))."""
+        if bool(on) != bool(self.keep_grads):
+            self.keep_grads = bool(on)
+            self._dw_desc.clear()            # the cached epilogue descriptors carry the flag
+
     def begin_step(self):
         """Forget the matrices registered by the previous enqueue of a step (the set is rebuilt as the backward is enqueued)."""
         self._dw_ranges = []
@@ -267,6 +273,11 @@ class FusedAdam(torch.optim.Optimizer):
         shape = ps.params[name].shape
         rows, K = dw.shape
         if len(shape) != 2 or K != shape[1] or dw.stride(0) != K or dw.stride(1) != 1 or (off - base) % K or name in ps.no_shadow:
+            return None
+        # the epilogue's own preconditions (vct_gemm's check_desc): 16-byte vectors of gradient / parameter / moments, 8-byte vectors of
+        # the shadow.  A matrix that fails them keeps its separate optimizer pass (its range is NOT registered) instead of aborting.
+        if K % 4 or off % 4 or (ps.flat.data_ptr() | self.exp_avg.data_ptr() | self.exp_avg_sq.data_ptr() | ps.gflat.data_ptr()) & 15 \
+                or ps.cflat.data_ptr() & 7:
             return None
         key = (off, rows, tuple(sorted(ps.packed)))
         ad = self._dw_desc.get(key)
@@ -459,8 +470,14 @@ class CaptionTrainer:
     to grow (engine.StepContext.generation), because they bake device pointers."""
 
     def __init__(self, model, optimizer, exchange: Optional[GradExchange] = None, use_graph: bool = False,
-                 launch_list: Optional[bool] = None):
+                 launch_list: Optional[bool] = None, keep_weight_grads: Optional[bool] = None):
+        """keep_weight_grads: on the single-GPU bf16 FusedAdam path the 2-D weights are stepped inside their weight-gradient GEMMs and
+        their gradients are NOT stored (model.grads_valid is False after a step; the reference leaves valid .grad after backward,
+        train.py:125).  True stores them as well (for clipping, logging, hooks; costs the 4 B per parameter the fusion saved);
+        None: the VCT_FUSE_ADAM_KEEP_GRAD environment switch (default off)."""
         self.model, self.opt, self.ex = model, optimizer, exchange
+        if keep_weight_grads is not None and isinstance(optimizer, FusedAdam):
+            optimizer.set_keep_grads(bool(keep_weight_grads))
         model._unit_loss_grad = True
         single = (exchange is None or not exchange.active) and isinstance(optimizer, FusedAdam)
         # a launch list can also carry the exchange when every collective is recordable: stream work of the library's own RCCL
