@@ -8,7 +8,7 @@
   configs[4]  greedy decode of the d=512 model at batch 1 / 16 against the reference's ids (fp32, free-running, compared up to the
               first step whose top-2 margin is below the fp32 resolution) and at batch 128 against the oracle; bf16 teacher-forced.
 
-Tolerances as in test_model_gpu.py (fp32: loss 1e-5 rel, gradients 1e-3; bf16: loss 1e-3, gradients 5e-2)."""
+Tolerances as in test_model_gpu.py (fp32: loss 1e-5 rel, gradients 1e-3; bf16: loss 1e-3, gradients 3e-2 = SURVEY 8(d); measured maximum over every tensor of every test 8.8e-3, profiles/r06_gpu_tests.txt)."""
 import json
 
 import numpy as np
@@ -16,7 +16,11 @@ import pytest
 import torch
 
 import vct_oracle as O
-from helpers import build_model, load_golden, model_config_of, rel
+from helpers import GradTol, build_model, load_golden, model_config_of, rel
+
+# bf16 tensors allowed above SURVEY 8(d)'s 3e-2 rel-Frobenius (they obey the test's own bound): filled in from the measured log
+# (profiles/r06_gpu_tests.txt); None = record only
+BF16_OVER_SURVEY = None
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -32,7 +36,7 @@ def _to_dev(*arrs):
     return [torch.from_numpy(a).to(DEV) for a in arrs]
 
 
-@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-2)])
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 3e-2)])
 def test_cfgD_deep_model_vs_reference(dtype, tl, tg):
     z = load_golden("cfgD_slices.npz")
     mc, V = model_config_of(z), int(z["vocab"])
@@ -55,12 +59,14 @@ def test_cfgD_deep_model_vs_reference(dtype, tl, tg):
         assert np.array_equal(lg.argmax(-1).cpu().numpy()[valid], z["logits_argmax"][valid])
     m._backward()
     names = json.loads(str(z["grad_names"]))
+    tol = GradTol("cfgD_deep_model_vs_reference(norms)", dtype, tg)
     for i, k in enumerate(names):
         g = m._ps.g[k]
         n = float(g.double().norm())
-        assert abs(n - z["grad_norms"][i]) < tg * z["grad_norms"][i] + 1e-9, (k, n, z["grad_norms"][i])
+        tol.add(k, abs(n - z["grad_norms"][i]) / max(float(z["grad_norms"][i]), 1e-30))
         head = np.resize(g.reshape(-1)[:32].cpu().numpy(), 32)
         assert np.abs(head - z["grad_heads"][i]).max() < tg * max(np.abs(z["grad_heads"][i]).max(), 1e-6) * 4 + 1e-8, k
+    tol.report()
 
 
 def test_cfgD_gradient_buckets_follow_the_backward_order():
@@ -94,7 +100,7 @@ def test_cfgD_gradient_buckets_follow_the_backward_order():
     assert sorted(ref_order) == sorted(n for n in ps.names if not n.startswith("matching"))
 
 
-@pytest.mark.parametrize("dtype,tg", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dtype,tg", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_cfgB_full_batch_256_vs_oracle(dtype, tg):
     mc = model_config_of(load_golden("cfgA_slices.npz"))           # the d=512 2+2 model of configs[0..2]
     V = 30522
@@ -126,13 +132,15 @@ def test_cfgB_full_batch_256_vs_oracle(dtype, tg):
     assert lerr < (1e-3 if dtype == torch.float32 else 2e-2), lerr
     del logits
     m._backward()
+    tol = GradTol("cfgB_full_batch_256_vs_oracle", dtype, tg, allow_over_survey=BF16_OVER_SURVEY)
     for k, g in ref_grads.items():
         mine = m._ps.g[k].double().cpu().numpy()
         r = float(np.linalg.norm(g.astype(np.float64)))
         assert abs(float(np.linalg.norm(mine)) - r) < tg * r + 1e-9, (k, r)
         # full tensors, not only norms: a mis-routed or permuted gradient with the right norm must fail
         err = float(np.linalg.norm(mine - g.astype(np.float64).reshape(mine.shape))) / max(r, 1e-30)
-        assert err < tg, (k, err)
+        tol.add(k, err)
+    tol.report()
     if dtype == torch.bfloat16:      # bitwise determinism of the full step at the benchmark batch (dropout 0.3 active)
         from vct_amd.trainer import CaptionTrainer, FusedAdam
         outs = []

@@ -4,7 +4,7 @@ against the golden vectors produced by the real reference, and against the CPU o
 Stated tolerances:
   fp32 mode : logits rel-Frobenius <= 1e-3 (measured ~1e-6), loss rel <= 1e-5, every parameter gradient
               rel-Frobenius <= 1e-3, greedy ids exact.
-  bf16 mode : logits <= 2e-2, loss rel <= 1e-3, gradients <= 5e-2 (floor from bf16 rounding of weights
+  bf16 mode : logits <= 2e-2, loss rel <= 1e-3, gradients <= 3e-2 (measured per-tensor maximum 8.8e-3, logged by helpers.GradTol; floor from bf16 rounding of weights
               and activations alone is ~6e-3 on logits)."""
 import json
 
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import vct_oracle as O
-from helpers import build_model, golden_params, load_golden, model_config_of, rel
+from helpers import GradTol, build_model, golden_params, load_golden, model_config_of, rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -49,7 +49,7 @@ def test_state_dict_surface():
     np.testing.assert_allclose(sd["video_encoder.temp_emb.pe"].cpu().numpy(), z["temp_pe"], atol=2e-5)
 
 
-@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 2e-2, 5e-2)])
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 2e-2, 3e-2)])
 def test_tiny_forward_backward_adam_vs_reference(dtype, tl, tg):
     z, mc, cfg, p = _tiny()
     m = build_model(mc, int(z["vocab"]), DEV, dtype, p)
@@ -74,11 +74,10 @@ def test_tiny_forward_backward_adam_vs_reference(dtype, tl, tg):
     loss2.backward()
     assert abs(float(loss2) - float(z["loss"])) < (1e-5 if dtype == torch.float32 else 2e-3) * float(z["loss"])
     named = dict(m.named_parameters())
-    worst = 0.0
+    tol = GradTol("tiny_forward_backward_adam_vs_reference", dtype, tg)
     for k in [k[len("grad/"):] for k in z.files if k.startswith("grad/")]:
-        e = rel(named[k].grad, z["grad/" + k])
-        worst = max(worst, e)
-        assert e < tg, (k, e)
+        tol.add(k, rel(named[k].grad, z["grad/" + k]))
+    tol.report()
     assert float(named["cap_decoder.tgt_to_emb.weight"].grad[0].abs().sum()) == 0.0
     opt.step()
     if dtype == torch.float32:
@@ -124,7 +123,7 @@ def test_ce_relu_variant():
         assert rel(m._ps.g[k], z["grad/" + k]) < 1e-3, k
 
 
-@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-2)])
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 3e-2)])
 def test_cfgA_full_size_vs_reference(dtype, tl, tg):
     """BASELINE.json configs[0]: d=512 2+2 layers, V=30522, B=8, T=12, S=20 -- reference slices."""
     z = load_golden("cfgA_slices.npz")
@@ -147,12 +146,14 @@ def test_cfgA_full_size_vs_reference(dtype, tl, tg):
         assert np.array_equal(lg.argmax(-1).cpu().numpy(), z["logits_argmax"])
     m._backward()
     names = json.loads(str(z["grad_names"]))
+    tol = GradTol("cfgA_full_size_vs_reference(norms)", dtype, tg)
     for i, k in enumerate(names):
         g = m._ps.g[k]
         n = float(g.double().norm())
-        assert abs(n - z["grad_norms"][i]) < tg * z["grad_norms"][i] + 1e-9, (k, n, z["grad_norms"][i])
+        tol.add(k, abs(n - z["grad_norms"][i]) / max(float(z["grad_norms"][i]), 1e-30))
         head = np.resize(g.reshape(-1)[:32].cpu().numpy(), 32)
         assert np.abs(head - z["grad_heads"][i]).max() < tg * max(np.abs(z["grad_heads"][i]).max(), 1e-6) * 4 + 1e-8, k
+    tol.report()
 
 
 def test_greedy_decode_ids_exact_fp32():
@@ -351,7 +352,7 @@ def test_graph_captured_train_step_matches_eager():
     assert outs[0][0][-1] < outs[0][0][0]      # and it learns
 
 
-@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 3e-2, 8e-2)])
+@pytest.mark.parametrize("dtype,tl,tg", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 3e-2, 3e-2)])
 def test_cfgD_deep_ragged_vs_oracle(dtype, tl, tg):
     """BASELINE.json configs[3] shape family (d=1024, head_dim 128, 32 frames, 40 tokens) with fewer layers and
     a small vocabulary so the CPU oracle finishes in seconds; ragged captions AND padded videos."""
@@ -371,8 +372,10 @@ def test_cfgD_deep_ragged_vs_oracle(dtype, tl, tg):
     assert rel(logits[:, :V].reshape(ref_logits.shape), ref_logits) < tl
     assert abs(float(loss) - ref_loss) < (1e-5 if dtype == torch.float32 else 2e-3) * abs(ref_loss)
     m._backward()
+    tol = GradTol("cfgD_deep_ragged_vs_oracle", dtype, tg)
     for k, g in ref_grads.items():
-        assert rel(m._ps.g[k], g) < tg, k
+        tol.add(k, rel(m._ps.g[k], g))
+    tol.report()
     if dtype == torch.float32:
         ys = m.greedy_decode_ids([feats[:2]], None, max_len=20)
         assert np.array_equal(ys.cpu().numpy(), O.greedy_decode_ids(p, cfg, f[:2], None, max_len=20))

@@ -1,4 +1,4 @@
-run() { tag="$1"; shift; python bench.py --no-cpu-baseline --no-decode --no-b1024 --no-other-configs --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "
+run() { tag="$1"; shift; python bench.py --no-cpu-baseline --no-decode --no-b1024 --no-other-configs --no-exchange-line --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print('$tag', j['value'], j['ms_per_step'])"; }
 for rep in 1 2; do

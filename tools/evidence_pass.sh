@@ -8,7 +8,7 @@ cd $R
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_list
-rocprofv3 --kernel-trace --stats -d /tmp/prof_list -o r -- python $R/bench.py --no-cpu-baseline --no-decode --no-b1024 --no-other-configs > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats -d /tmp/prof_list -o r -- python $R/bench.py --no-cpu-baseline --no-decode --no-b1024 --no-other-configs --no-exchange-line > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 cd $R
 db=$(find /tmp/prof_list -name "*results.db" | head -1)
 python tools/rocpd_summary.py $db --skip-frac 0.35 > $OUT/bench_list_kernel_summary.txt 2>&1

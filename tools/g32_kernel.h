@@ -1,0 +1,433 @@
+// DEV PROBE, NOT PART OF THE LIBRARY (round 6; measured and rejected IN THE STEP).
+// Persistent 256x256-tile bf16 GEMM, second generation: gemm256_kernel's structure (vct_gemm256.hip: one workgroup per CU
+// walking a flat stream of (work item, K stage) steps, two 64-deep stages of 64 KB in LDS, 8 waves as 2 x 4, accumulators transposed
+// per MFMA tile) with a K loop that is software-pipelined at k-step granularity on v_mfma_f32_32x32x16_bf16.
+//
+// Why.  Ablations of gemm256_kernel (profiles/r06_g256_ablate_shipped.txt, profiles/r06_g32_probe_ablations.txt): MFMAs + fragment
+// reads ALONE take 127-148 us on the three vocabulary products whose MFMA work is 61 us at peak (~80 us at the clock the part sustains
+// on random data) -- after every stage barrier all eight waves first read fragments (nothing to issue on the matrix pipe), then all
+// of them have MFMAs, then all wait at the next barrier.  Here
+//   * a wave's 128 x 64 piece = 4 x 2 tiles of 32 x 32; a stage = 4 k-steps of 16, 8 MFMAs each; the fragments of k-step j+1
+//     (6 ds_read_b128 / 12 transpose reads, 24 VGPRs) are read BETWEEN the MFMAs of k-step j into the other half of a double buffer
+//     -- 48 fragment registers instead of the 96 the same scheme needs on 16x16x32 (two k-steps of 32 per stage: that variant spills
+//     41 registers and runs 40 % slower; without the epilogue, where it does not spill, the two opcodes are equal: 97 vs 102 us);
+//   * the stage barrier sits IN FRONT OF THE LAST k-step: by then every fragment of the stage is in registers (its buffer is free for
+//     the DMA of stage s+2) and stage s+1 has landed, so the first fragments of stage s+1 are read under the last k-step's MFMAs and
+//     the matrix pipe has work on both sides of the barrier: compute loop 127-148 -> 97-102 us;
+//   * operand DMA = buffer_load_dwordx4 ... lds: the lane's byte offset (row x leading dimension, swizzled chunk) is fixed per tile
+//     in 8 VGPRs, the K offset rides in the instruction's SGPR offset -- no address arithmetic in the K loop;
+//   * LDS images (lane-linear as the DMA requires; the swizzle is applied to the SOURCE address and, identically, on the read):
+//       K-contiguous operand   [256 rows][64 k]: 16-byte chunk c of row r at c ^ ((r >> 1) & 7): lanes 0-31 of a 32-row fragment read
+//                              32 consecutive rows at ONE chunk -- conflict-free over ds_read_b128's 16-lane groups;
+//       M/N-contiguous operand [64 k][256 cols]: 32-byte block b of k-row r at b ^ f(r), f = rotate-left-1 of r's low three bits
+//                              (| r & 8): the 32 lanes of one LDS cycle of ds_read_b64_tr_b16 cover two adjacent blocks x four
+//                              consecutive k-rows = eight distinct block positions mod 8.  (gemm256_kernel's NN form: 24 % of its
+//                              LDS cycles are bank conflicts, its r & 15 swizzle maps k-rows r and r + 8 onto the same banks.)
+//   * the 64 DMA instructions of a stage are not issued in one burst: 2 per wave ride between the MFMAs of the last k-step, 3 + 3
+//     open k-steps 0 and 1 of the NEXT stage (their buffer is free from the barrier on and is read again only after the next one):
+//     issued together they queue behind the CU's vector-memory port (64 B/clk) and every wave sits in "issue" instead of in its MFMAs
+//     -- the NN form lost 63 us to that, more than the 39 us the whole DMA stream takes alone;
+//   * a ragged last K stage takes a zero-filling register path into the same images; the epilogue is gemm256_kernel's (row slab in
+//     the stage just consumed, whole-row stores), fp32 partials for the K-split forms.
+// Measured against gemm256_kernel, same process, same data (tools/g32_probe.hip): NT 4096^3 1190-1250 -> 1250-1300 TF, vocabulary
+// projection 171-177 -> 161-169 us; bit-identical outputs.
+#pragma once
+// (included by tools/g32_probe.hip behind vct_gemm256.hip, which defines G256P, G256_STAGE, persistent_grid ...)
+
+namespace vct {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int kc32_swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int mc32_swz(int krow) { return ((krow & 3) << 1) | ((krow >> 2) & 1) | (krow & 8); }
+
+// ragged last K stage: predicated 16-byte loads (zero fill beyond K / beyond the operand's rows) into the swizzled image
+template <bool MC, int NT>
+__device__ __forceinline__ void tail_tile32(unsigned char* img, const bf16_t* __restrict__ base, long ld, int r0, int r_ext, int k0, int K, int tid) {
+  constexpr int NV = 256 * 8 / NT;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int v = tid + i * NT;
+    V16b val; val.w[0] = val.w[1] = val.w[2] = val.w[3] = 0u;
+    if constexpr (!MC) {
+      const int row = v >> 3, c = v & 7;
+      const int gr = r0 + row, gk = k0 + c * 8;
+      if (gr < r_ext && gk < K) {
+        val = *reinterpret_cast<const V16b*>(base + (long)gr * ld + gk);
+        if (gk + 8 > K) {
+          const int keep = K - gk;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (2 * q >= keep) val.w[q] = 0u;
+            else if (2 * q + 1 >= keep) val.w[q] &= 0xffffu;
+          }
+        }
+      }
+      *reinterpret_cast<V16b*>(img + row * 128 + ((c ^ kc32_swz(row)) << 4)) = val;
+    } else {
+      const int krow = v >> 5, p = v & 31;                     // 32 sixteen-byte pieces per k-row
+      const int col = p * 8;
+      const int gk = k0 + krow, gr = r0 + col;
+      if (gk < K && gr < r_ext) val = *reinterpret_cast<const V16b*>(base + (long)gk * ld + gr);
+      *reinterpret_cast<V16b*>(img + krow * 512 + ((((p >> 1) ^ mc32_swz(krow)) << 1) | (p & 1)) * 16) = val;
+    }
+  }
+}
+
+// The caller's G256P (vct_gemm256.hip, which includes this file) is reused: same work-item order, same output conventions.
+template <int TA, int TB, typename TO, int VAR>
+__global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
+  constexpr bool A_MC = (TA == 1), B_MC = (TB == 0);
+  constexpr bool BG = (TA == 1 && TB == 0);
+  constexpr int T = 32, NSTEP = 4, TM = 4, TN = 2;
+  constexpr int NT = 512, WM = 128;
+  constexpr int ES = (int)sizeof(TO);
+  constexpr int STAGE = G256_STAGE, A_BYTES = G256_BM * 128;
+  constexpr int RPR = STAGE / (G256_BN * ES);                      // slab rows per round: 128 (bf16) / 64 (fp32)
+  constexpr int CPRW = G256_BN * ES / 16;                          // 16-byte chunks per slab row
+  constexpr int CPT = RPR * CPRW / NT;                             // chunks per thread and round
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  if constexpr (VAR & 1) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+
+  const int nitems = p.tiles_m * p.tiles_n * p.split;
+  const int nxw = (int)gridDim.x >> 3;
+  const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int w_begin = xcd * per, w_end = min(nitems, w_begin + per);
+  const int nkt = (p.K + BK2 - 1) / BK2, kt_full = p.K / BK2;
+
+  auto item = [&](int w, int& m0, int& n0, int& z, int& k_lo, int& k_hi) {
+    int tile;
+    if (p.zmajor) { const int nt = p.tiles_m * p.tiles_n; z = w / nt; tile = w - z * nt; }
+    else { tile = w / p.split; z = w - tile * p.split; }
+    if (p.order == 0) {
+      m0 = (tile % p.tiles_m) * G256_BM; n0 = (tile / p.tiles_m) * G256_BN;
+    } else {
+      const int per_group = 8 * p.tiles_m;
+      const int grp = tile / per_group, rem = tile - grp * per_group;
+      const int gw = min(8, p.tiles_n - grp * 8);
+      m0 = (rem / gw) * G256_BM; n0 = (grp * 8 + rem % gw) * G256_BN;
+    }
+    k_lo = z * p.kt_per_split; k_hi = min(nkt, k_lo + p.kt_per_split);
+  };
+
+  // ---- operand DMA: 4 + 4 one-KiB pieces per wave and stage; voff = byte offset of the lane's 16 bytes at K offset 0 ----
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7fffffff, 0x00020000);
+  const int lda32 = (int)p.lda, ldb32 = (int)p.ldb;               // (operands < 2 GiB: g32_eligible)
+  const int kstrA = A_MC ? 128 * lda32 : 128, kstrB = B_MC ? 128 * ldb32 : 128;   // bytes per K stage
+  int voff[8];
+  auto set_voff = [&](int m0, int n0) {
+    int l = lane;
+    asm volatile("" : "+v"(l));                                    // opaque: nothing of this is hoisted out of the item loop and kept alive
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int ci = (q & 3) * 8 + wave;
+      const bool mc = q < 4 ? A_MC : B_MC;
+      const int r0 = q < 4 ? m0 : n0, ext = q < 4 ? p.M : p.N, ld = q < 4 ? lda32 : ldb32;
+      if (!mc) {
+        const int row = ci * 8 + (l >> 3);
+        const int c = (l & 7) ^ kc32_swz(row);
+        voff[q] = (min(r0 + row, ext - 1) * ld + c * 8) * 2;
+      } else {
+        const int krow = ci * 2 + (l >> 5), pp = l & 31;
+        const int col = ((((pp >> 1) ^ mc32_swz(krow)) << 1) | (pp & 1)) * 8;
+        const int rlim = ((ext + 7) & ~7) - 8;                     // last fully readable vector (ld covers the rounded-up extent)
+        voff[q] = (krow * ld + min(r0 + col, rlim)) * 2;
+      }
+    }
+  };
+  auto dma = [&](auto Q, unsigned char* stage_buf, int kt) {
+    constexpr int q = decltype(Q)::value;
+    const int ci = (q & 3) * 8 + wave;
+    unsigned char* dst = stage_buf + (q >= 4 ? A_BYTES : 0) + ci * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(q >= 4 ? rsB : rsA, (__attribute__((address_space(3))) void*)dst, 16, voff[q],
+                                             kt * (q >= 4 ? kstrB : kstrA), 0, 0);
+  };
+  auto tail_stage = [&](unsigned char* stage_buf, int m0, int n0, int kt) {      // ragged stage: register path, every thread
+    tail_tile32<A_MC, NT>(stage_buf, A, p.lda, m0, p.M, kt * BK2, p.K, tid);
+    tail_tile32<B_MC, NT>(stage_buf + A_BYTES, B, p.ldb, n0, p.N, kt * BK2, p.K, tid);
+  };
+
+  // ---- fragments: per-lane LDS byte offsets at k-step 0, tile 0 ----
+  // K-contiguous: lane = row (lane & 31), chunk = step * 2 + (lane >> 5); the k-step flips bits 5-6 of the offset, tiles add immediates.
+  // M/N-contiguous: two transpose reads per fragment (k-rows +0..3, +4..7 of the lane half's eight); within a 16-lane group lane 4r + c
+  // points at columns 4c..4c+3 of k-row r; the k-step adds 8 KiB, the tile flips bits 6-7 (block index + 2 per 32 columns).
+  const int rl = lane & 31, hl = lane >> 5;
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  int offA, offA2 = 0, offB, offB2 = 0;
+  if constexpr (!A_MC) { const int r = wm * WM + rl; offA = r * 128 + ((hl ^ kc32_swz(r)) << 4); }
+  else {
+    const int kr = hl * 8 + (i16 >> 2), blk = wm * 8 + g16;
+    offA = kr * 512 + ((blk ^ mc32_swz(kr)) << 5) + (i16 & 3) * 8;
+    offA2 = (kr + 4) * 512 + ((blk ^ mc32_swz(kr + 4)) << 5) + (i16 & 3) * 8;
+  }
+  if constexpr (!B_MC) { const int r = wn * 64 + rl; offB = A_BYTES + r * 128 + ((hl ^ kc32_swz(r)) << 4); }
+  else {
+    const int kr = hl * 8 + (i16 >> 2), blk = wn * 4 + g16;
+    offB = A_BYTES + kr * 512 + ((blk ^ mc32_swz(kr)) << 5) + (i16 & 3) * 8;
+    offB2 = A_BYTES + (kr + 4) * 512 + ((blk ^ mc32_swz(kr + 4)) << 5) + (i16 & 3) * 8;
+  }
+  bf16x8 fa[2][TM], fb[2][TN];
+  auto read_one = [&](auto MCT, const unsigned char* sb, int o1, int o2, int step, int t) -> bf16x8 {
+    if constexpr (!decltype(MCT)::value) {
+      return *reinterpret_cast<const bf16x8*>(sb + (o1 ^ (step << 5)) + t * T * 128);
+    } else {
+      const s16x4 lo = lds_tr16(reinterpret_cast<const bf16_t*>(sb + (o1 ^ (t << 6)) + step * 8192));
+      const s16x4 hi = lds_tr16(reinterpret_cast<const bf16_t*>(sb + (o2 ^ (t << 6)) + step * 8192));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto read_frags = [&](auto SET, const unsigned char* sb, int step) {
+    constexpr int st = decltype(SET)::value;
+    int oa = offA, oa2 = offA2, ob = offB, ob2 = offB2;
+    asm volatile("" : "+v"(oa), "+v"(oa2), "+v"(ob), "+v"(ob2));  // (per-step / per-tile variants are recomputed, not hoisted and spilled)
+#pragma unroll
+    for (int j = 0; j < TN; j++) fb[st][j] = read_one(std::integral_constant<bool, B_MC>{}, sb, ob, ob2, step, j);
+#pragma unroll
+    for (int i = 0; i < TM; i++) fa[st][i] = read_one(std::integral_constant<bool, A_MC>{}, sb, oa, oa2, step, i);
+  };
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  };
+  // accumulators hold C TRANSPOSED per MFMA tile (operands swapped): lane = row i * 32 + (lane & 31) of the wave's piece, register
+  // 4q + r = column j * 32 + q * 8 + (lane >> 5) * 4 + r
+  auto mfma_step = [&](auto SET) {
+    constexpr int st = decltype(SET)::value;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st][j], fa[st][i], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NRD = TM * (A_MC ? 2 : 1) + TN * (B_MC ? 2 : 1), NMF = TM * TN;   // LDS reads / MFMAs per k-step
+  zero_acc();
+  // bias of the lane's columns (groups of four consecutive columns, index j * 4 + q)
+  constexpr int NBG = TN * 4;
+  f32x4 bj[NBG];
+  // bias gradient (weight-gradient form) = row sums of op(A): the four waves of a row group hold the same A fragments, wave wn sums
+  // tile row i == wn (16 VALU per k-step and wave; the round-5 kernel's wn == 0 waves did all four rows, 64 conversions + adds per
+  // k-step, and the other six waves waited for them at every stage barrier)
+  float accb[BG ? TM : 1];
+#pragma unroll
+  for (int i = 0; i < (BG ? TM : 1); i++) accb[i] = 0.0f;
+  int n0 = 0;
+  auto load_bias = [&]() {
+    int h = hl;
+    asm volatile("" : "+v"(h));
+#pragma unroll
+    for (int g = 0; g < NBG; g++) {
+      const int col = n0 + wn * 64 + (g >> 2) * T + (g & 3) * 8 + h * 4;
+      if (p.bias == nullptr || p.partial != nullptr) bj[g] = f32x4{0, 0, 0, 0};
+      else if (col + 4 <= p.N) bj[g] = *reinterpret_cast<const f32x4*>(p.bias + col);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) bj[g][r] = p.bias[min(col + r, p.N - 1)];
+      }
+    }
+  };
+  auto bias_grad_step = [&](auto SET) {
+    if constexpr (BG) {
+      constexpr int st = decltype(SET)::value;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const s16x8 v = __builtin_bit_cast(s16x8, fa[st][i]);
+        float t = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) t += bf2f((bf16_t)v[u]);
+        accb[i] += t;
+      }
+    }
+  };
+
+  int w = w_begin + slot;
+  int m0 = 0, z = 0, k_lo = 0, k_hi = 0;
+  int buf = 0;
+  int pend_kt = -1;                 // K stage whose DMA pieces 2..7 are still to be issued (into the buffer that is NOT being read)
+  if (w < w_end) {
+    item(w, m0, n0, z, k_lo, k_hi);
+    set_voff(m0, n0);
+    static_for<8>([&](auto Q) { dma(Q, lds, k_lo); });              // (every item starts with two full stages: g32_eligible)
+    static_for<8>([&](auto Q) { dma(Q, lds + STAGE, k_lo + 1); });
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(std::integral_constant<int, 0>{}, lds, 0);
+  }
+  for (; w < w_end; w += nxw) {
+    int m1 = 0, n1 = 0, z1 = 0, k1_lo = 0, k1_hi = 0;
+    const bool have_next = w + nxw < w_end;
+    if (have_next) item(w + nxw, m1, n1, z1, k1_lo, k1_hi);
+    const bool do_bg = BG && p.bias_grad != nullptr && n0 == 0 && wn == 0;
+    for (int kt = k_lo; kt < k_hi; kt++) {
+      unsigned char* sb = lds + buf * STAGE;
+      unsigned char* nb = lds + (buf ^ 1) * STAGE;
+      const bool last = kt + 1 == k_hi;
+      if (last) load_bias();                                        // in flight under this stage; the barrier's vmcnt(0) covers them
+      // ---- k-steps 0 .. 2: MFMAs of step j, reads of step j+1 between them ----
+      static_for<NSTEP - 1>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < 2) {                                       // the rest of the DMA group opened in the previous stage's last k-step
+          if (pend_kt >= 0) static_for<3>([&](auto U) { dma(std::integral_constant<int, 2 + j * 3 + decltype(U)::value>{}, nb, pend_kt); });
+          if constexpr (j == 1) pend_kt = -1;
+        }
+        read_frags(std::integral_constant<int, (j + 1) & 1>{}, sb, j + 1);
+        mfma_step(std::integral_constant<int, j & 1>{});
+        static_for<NMF>([&](auto I) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          constexpr int lo = decltype(I)::value * NRD / NMF, hi = (decltype(I)::value + 1) * NRD / NMF;
+          if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(0x100, hi - lo, 0);
+        });
+        if (do_bg) bias_grad_step(std::integral_constant<int, j & 1>{});
+      });
+      // ---- every fragment of this stage is in registers, the next stage has landed: barrier ----
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---- last k-step: first fragments of stage s+1, MFMAs, DMA of stage s+2 into this buffer between them.  ONE MFMA path: the
+      // wave-uniform conditions only guard the small read / DMA blocks (three copies of the step made hipcc shuffle and spill whole
+      // accumulators at the joins).  The LAST stage of an item keeps its buffer for the epilogue's row slab: its DMA follows that. ----
+      const bool own2 = kt + 2 < k_hi;
+      const int kt2 = own2 ? kt + 2 : k1_lo;
+      const int m2 = own2 ? m0 : m1, n2 = own2 ? n0 : n1;
+      const bool nx1 = !last || have_next;
+      const bool nx2 = !last && (own2 || have_next) && !(VAR & 8);
+      const bool nx2_dma = nx2 && kt2 < kt_full;
+      if (kt == k_hi - 2 && have_next) set_voff(m1, n1);            // (every DMA from here on belongs to the next item)
+      if (nx2 && !nx2_dma) tail_stage(sb, m2, n2, kt2);
+      if (nx1) read_frags(std::integral_constant<int, 0>{}, nb, 0);
+      static_for<TM>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+        if constexpr (i == 1 || i == 3) { if (nx2_dma) dma(std::integral_constant<int, i / 2>{}, sb, kt2); }
+      });
+      if (nx2_dma) pend_kt = kt2;
+      if (do_bg) bias_grad_step(std::integral_constant<int, 1>{});
+      buf ^= 1;
+    }
+    // ---- epilogue: the stage just consumed (buf ^ 1) is free (its DMA was held back): the row slab lives there ----
+    unsigned char* slab = lds + (buf ^ 1) * STAGE;
+    const bool part = p.partial != nullptr;
+    if constexpr (BG) {
+      if (do_bg) {                                                  // the two lane halves hold the two halves of every k-step's k's
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          float t = accb[i];
+          t += __shfl_xor(t, 32);
+          const int row = m0 + wm * WM + i * T + rl;
+          if (hl == 0 && row < p.M) (part ? p.partial + (size_t)p.split * p.M * p.N + (size_t)z * p.M : p.bias_grad)[row] = t;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++) accb[i] = 0.0f;
+    }
+    float* pc = part ? p.partial + (size_t)z * (size_t)p.M * (size_t)p.N : nullptr;
+    const long ldo = part ? (long)p.N : p.ldc;
+    constexpr int MTR = RPR / (2 * T);                              // MFMA tile rows per wave and round: 2 (bf16) / 1 (fp32)
+    // opaque copies of the lane coordinates: the slab offsets / output coordinates below depend on the lane only, and hipcc otherwise
+    // computes all of them at kernel entry, spills them across the K loops and reloads them (10 scratch loads, a round trip each) here
+    int e_rl = rl, e_hl = hl, e_tid = tid;
+    asm volatile("" : "+v"(e_rl), "+v"(e_hl), "+v"(e_tid));
+    if constexpr (VAR & 4) {                                        // (ablation: no epilogue; the accumulators stay live at 128 adds per tile)
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) t += acc[i][j][r];
+      if (t == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = t;
+    } else
+    static_for<TM / MTR>([&](auto RD) {
+      constexpr int rd = decltype(RD)::value;
+      if constexpr (rd > 0) lds_barrier();                          // the slab has been read out by everyone
+#pragma unroll
+      for (int ii = 0; ii < MTR; ii++) {
+        const int sr = (wm * MTR + ii) * T + e_rl;                    // slab row; 16-byte chunk c of row r sits at c ^ (r & 31)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {                             // groups of four consecutive columns
+            const int e0 = wn * 64 + j * T + q * 8 + e_hl * 4;
+            const f32x4 bv = bj[j * 4 + q];
+            if constexpr (ES == 2) {
+              struct alignas(8) B4 { bf16_t e[4]; } v;
+#pragma unroll
+              for (int r = 0; r < 4; r++) v.e[r] = f2bf(acc[rd * MTR + ii][j][q * 4 + r] + bv[r]);
+              const int g8 = e0 >> 2;
+              *reinterpret_cast<B4*>(slab + sr * (G256_BN * 2) + ((((g8 >> 1) ^ (sr & 31)) << 1) | (g8 & 1)) * 8) = v;
+            } else {
+              f32x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; r++) v[r] = acc[rd * MTR + ii][j][q * 4 + r] + bv[r];
+              *reinterpret_cast<f32x4*>(slab + sr * (G256_BN * 4) + (((e0 >> 2) ^ (sr & 31)) << 4)) = v;
+            }
+          }
+        }
+      }
+      lds_barrier();
+#pragma unroll 2
+      for (int q = 0; q < CPT; q++) {
+        const int cid = q * NT + e_tid;
+        const int sr = cid / CPRW, c = cid % CPRW;
+        const int row = m0 + (sr / (MTR * T)) * WM + (rd * MTR + ((sr / T) % MTR)) * T + (sr % T);
+        constexpr int EPC = 16 / ES;
+        const int col = n0 + c * EPC;
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + sr * (G256_BN * ES) + ((c ^ (sr & 31)) << 4));
+        if (row < p.M && col < p.N) {
+          TO* dst = (part ? reinterpret_cast<TO*>(pc) : reinterpret_cast<TO*>(p.C)) + (size_t)row * ldo + col;
+          if (col + EPC <= p.N && (ldo % EPC) == 0) *reinterpret_cast<u32x4*>(dst) = v;
+          else {
+            const TO* e = reinterpret_cast<const TO*>(&v);
+            for (int qq = 0; qq < EPC; qq++) if (col + qq < p.N) dst[qq] = e[qq];
+          }
+        }
+      }
+    });
+    zero_acc();
+    // the slab has been read out by everyone: the held-back stage (second stage of the next item) goes into it
+    if (have_next) {
+      lds_barrier();
+      if (k1_lo + 1 < k1_hi && !(VAR & 8)) {
+        if (k1_lo + 1 < kt_full) static_for<8>([&](auto Q) { dma(Q, slab, k1_lo + 1); });
+        else tail_stage(slab, m1, n1, k1_lo + 1);
+      }
+    }
+    m0 = m1; n0 = n1; z = z1; k_lo = k1_lo; k_hi = k1_hi;
+  }
+}
+
+template <int TA, int TB, typename TO, int VAR> static int g32_launch(const G256P& p, hipStream_t st) {
+  static vct::DynLdsOptIn optin;
+  if (hipError_t e = optin.ensure((const void*)g32_kernel<TA, TB, TO, VAR>, G256_LDS); e != hipSuccess) return (int)e;
+  vct::launch(g32_kernel<TA, TB, TO, VAR>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
+  VCT_CHECK_LAUNCH();
+  return VCT_OK;
+}
+
+// What the pipelined kernel needs beyond gemm256_try's own rules: every work item starts with two FULL K stages (its prologue and the
+// hand-over from the previous item are DMA stages), and operand byte offsets fit the buffer instructions' 32-bit offsets.
+static inline bool g32_eligible(const G256P& p, bool a_mc, bool b_mc) {
+  const int kt_full = p.K / 64, nkt = (p.K + 63) / 64;
+  for (int z = 0; z < p.split; z++) {
+    const int lo = z * p.kt_per_split, hi = lo + p.kt_per_split < nkt ? lo + p.kt_per_split : nkt;
+    if (hi - lo < 2 || lo + 2 > kt_full) return false;
+  }
+  const long a_bytes = (a_mc ? (long)p.K : (long)p.M) * p.lda * 2, b_bytes = (b_mc ? (long)p.K : (long)p.N) * p.ldb * 2;
+  return a_bytes < 0x7fffffffL && b_bytes < 0x7fffffffL;
+}
+
+}  // namespace vct

@@ -18,8 +18,9 @@ void rec_push(hipStream_t, std::function<void(hipStream_t)>&&) {}
 void replay_note_error(int) {}
 }  // namespace vct
 
-#include "../video-captioning-transformer_amd/csrc/vct_gemm32_kernel.h"
 
+#include "g32_kernel.h"
+#include "g32_kernel_v1.h"
 using namespace vct;
 
 static uint16_t f2bf_host(float f) {
@@ -29,90 +30,146 @@ static uint16_t f2bf_host(float f) {
 }
 static float bf2f_host(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int TA, int TB, typename TO> static void base_launch(const G256P& p, hipStream_t st) { g256_launch<TA, TB, TO>(p, st); }
+// the round-5 kernel, directly (g256_launch dispatches to the pipelined one by default)
+template <int TA, int TB, typename TO> static void base_launch(const G256P& p, hipStream_t st) {
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute((const void*)gemm256_kernel<TA, TB, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS); once = true; }
+  hipLaunchKernelGGL((gemm256_kernel<TA, TB, TO>), dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
+}
 
-struct Shape { const char* name; int M, N, K; };
+struct Shape { const char* name; int ta, tb, M, N, K, split; };
+
+template <typename TO> static double cmp(const std::vector<TO>& a, const std::vector<TO>& b, long rows, long cols, long ld, long* nbad) {
+  double maxd = 0; *nbad = 0;
+  for (long r = 0; r < rows; r++)
+    for (long c = 0; c < cols; c++) {
+      double x, y;
+      if constexpr (sizeof(TO) == 2) { x = bf2f_host(a[r * ld + c]); y = bf2f_host(b[r * ld + c]); }
+      else { x = a[r * ld + c]; y = b[r * ld + c]; }
+      const double d = fabs(x - y);
+      if (!(d <= 0.02 * (1.0 + fabs(x)))) (*nbad)++;
+      if (d > maxd) maxd = d;
+    }
+  return maxd;
+}
+
+template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hipStream_t st, int iters, int rounds) {
+  const int M = s.M, N = s.N, K = s.K;
+  const long Kp = (K + 7) / 8 * 8, Mp = (M + 7) / 8 * 8, Np = (N + 7) / 8 * 8;
+  const long lda = TA ? Mp : Kp, ldb = TB ? Kp : Np, ldc = Np;
+  const long arows = TA ? K : M, brows = TB ? N : K;
+  std::vector<uint16_t> ha((size_t)arows * lda), hb((size_t)brows * ldb);
+  uint32_t seed = 12345u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : ha) v = f2bf_host(rnd());                        // (padding columns hold random, finite values too)
+  for (auto& v : hb) v = f2bf_host(rnd() * 0.05f);
+  std::vector<float> hbias(N);
+  for (auto& v : hbias) v = rnd();
+  const int split = s.split;
+  const size_t out_elems = split > 1 ? (size_t)split * M * N : (size_t)M * ldc;
+  uint16_t *dA, *dB; TO *dC0, *dC1; float *dbias, *dbg0, *dbg1;
+  hipMalloc(&dA, ha.size() * 2 + 4096); hipMalloc(&dB, hb.size() * 2 + 4096); hipMalloc(&dC0, out_elems * sizeof(TO)); hipMalloc(&dC1, out_elems * sizeof(TO));
+  hipMalloc(&dbias, N * 4); hipMalloc(&dbg0, M * 4); hipMalloc(&dbg1, M * 4);
+  hipMemcpy(dA, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice);
+  G256P p; memset(&p, 0, sizeof(p));
+  p.A = dA; p.B = dB; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256;
+  const int nkt = (K + 63) / 64;
+  p.kt_per_split = (nkt + split - 1) / split; p.split = (nkt + p.kt_per_split - 1) / p.kt_per_split;
+  p.order = 1; p.zmajor = split > 1 ? 1 : 0;
+  const bool nt_plain = (TA == 0 && TB == 1 && split == 1);
+  p.bias = nt_plain ? dbias : nullptr;
+  struct Var { const char* name; std::function<void(TO*, float*)> run; };
+  std::vector<Var> vars;
+  auto prep = [&](TO* c, float* bg) { G256P q = p; if (split > 1) q.partial = reinterpret_cast<float*>(c); else q.C = c; if (TA == 1 && TB == 0) q.bias_grad = bg; return q; };
+  vars.push_back({"round-5 gemm256", [&](TO* c, float* bg) { base_launch<TA, TB, TO>(prep(c, bg), st); }});
+  vars.push_back({"pipelined 32x32x16", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 0>(prep(c, bg), st); }});
+  if constexpr (TA == 0 && TB == 1 && sizeof(TO) == 2)
+    vars.push_back({"pipelined v1 (first probe)", [&](TO* c, float* bg) { g32v1_launch<0, 1, bf16_t, 32, 0>(prep(c, bg), st); }});
+  else
+  vars.push_back({"pipelined, prio", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 1>(prep(c, bg), st); }});
+  if constexpr (TA == 1) {
+    vars.push_back({"r5, no bias grad", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.bias_grad = nullptr; base_launch<TA, TB, TO>(q, st); }});
+    vars.push_back({"pipelined, no bias grad", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.bias_grad = nullptr; g32_launch<TA, TB, TO, 0>(q, st); }});
+    vars.push_back({"pipelined, no bias grad, no epi no DMA", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.bias_grad = nullptr; g32_launch<TA, TB, TO, 12>(q, st); }});
+  }
+  vars.push_back({"ablate r5: no epilogue", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.dbg = 4; base_launch<TA, TB, TO>(q, st); }});
+  vars.push_back({"ablate pipelined: no epilogue", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 4>(prep(c, bg), st); }});
+  vars.push_back({"ablate r5: no epi no DMA", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.dbg = 6; base_launch<TA, TB, TO>(q, st); }});
+  vars.push_back({"ablate pipelined: no epi no DMA", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 12>(prep(c, bg), st); }});
+  printf("[%s] eligible for the pipelined kernel: %d (split %d x %d stages)\n", s.name, (int)g32_eligible(prep(dC0, dbg0), TA == 1, TB == 0), p.split, p.kt_per_split);
+  // ---- correctness: the first three against the round-5 kernel everywhere and a host fp64 reference on a lattice ----
+  hipMemset(dC0, 0, out_elems * sizeof(TO)); hipMemset(dbg0, 0, M * 4);
+  vars[0].run(dC0, dbg0); hipStreamSynchronize(st);
+  std::vector<TO> c0(out_elems), c1(out_elems);
+  std::vector<float> g0(M), g1(M);
+  hipMemcpy(c0.data(), dC0, out_elems * sizeof(TO), hipMemcpyDeviceToHost); hipMemcpy(g0.data(), dbg0, M * 4, hipMemcpyDeviceToHost);
+  for (size_t v = 0; v < 3; v++) {
+    hipMemset(dC1, 0xff, out_elems * sizeof(TO)); hipMemset(dbg1, 0xff, M * 4);
+    vars[v].run(dC1, dbg1); hipStreamSynchronize(st);
+    const hipError_t e = hipGetLastError();
+    hipMemcpy(c1.data(), dC1, out_elems * sizeof(TO), hipMemcpyDeviceToHost); hipMemcpy(g1.data(), dbg1, M * 4, hipMemcpyDeviceToHost);
+    long nbad = 0; double maxd;
+    if (split > 1) maxd = cmp<TO>(c0, c1, (long)split * M, N, N, &nbad); else maxd = cmp<TO>(c0, c1, M, N, ldc, &nbad);
+    double maxe = 0, maxg = 0;
+    for (int r = 0; r < M; r += 397)
+      for (int c = 0; c < N; c += 61) {
+        double acc = nt_plain ? hbias[c] : 0.0;
+        for (int k = 0; k < K; k++) {
+          const double a = bf2f_host(TA ? ha[(size_t)k * lda + r] : ha[(size_t)r * lda + k]);
+          const double b = bf2f_host(TB ? hb[(size_t)c * ldb + k] : hb[(size_t)k * ldb + c]);
+          acc += a * b;
+        }
+        double got = 0;
+        if (split > 1) { for (int z = 0; z < p.split; z++) got += (double)*reinterpret_cast<float*>(&c1[((size_t)z * M + r) * N + c]); }
+        else if constexpr (sizeof(TO) == 2) got = bf2f_host(c1[(size_t)r * ldc + c]);
+        else got = c1[(size_t)r * ldc + c];
+        const double d = fabs(acc - got) / (1.0 + fabs(acc));
+        if (d > maxe) maxe = d;
+      }
+    if (TA == 1 && TB == 0)
+      for (int r = 0; r < M; r += 97) {
+        double acc = 0;
+        for (int k = 0; k < K; k++) acc += bf2f_host(ha[(size_t)k * lda + r]);
+        const double d = fabs(acc - g1[r]) / (1.0 + fabs(acc));
+        if (d > maxg) maxg = d;
+      }
+    printf("[%s] %-32s err=%d  vs round 5: max|d| %.4g bad %ld   vs fp64 lattice: max rel %.4g   bias-grad max rel %.3g\n", s.name, vars[v].name, (int)e, maxd, nbad, maxe, maxg);
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int r = 0; r < rounds; r++)
+    for (size_t v = 0; v < vars.size(); v++) {
+      for (int i = 0; i < 3; i++) vars[v].run(dC1, dbg1);
+      hipEventRecord(e0, st);
+      for (int i = 0; i < iters; i++) vars[v].run(dC1, dbg1);
+      hipEventRecord(e1, st); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms * 1e3 / iters;
+      printf("[%s] round %d %-32s %8.1f us  %7.1f TF\n", s.name, r, vars[v].name, us, 2.0 * M * N * K / us / 1e6);
+    }
+  hipFree(dA); hipFree(dB); hipFree(dC0); hipFree(dC1); hipFree(dbias); hipFree(dbg0); hipFree(dbg1);
+  fflush(stdout);
+}
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
   const int rounds = argc > 2 ? atoi(argv[2]) : 3;
-  Shape shapes[] = {{"square 4096^3", 4096, 4096, 4096}, {"gen_fwd 4864x30522x512", 4864, 30522, 512}, {"ragged 1000x3001x512", 1000, 3001, 512}};
+  const char* only = argc > 3 ? argv[3] : "";
+  Shape shapes[] = {
+      {"NT square 4096^3", 0, 1, 4096, 4096, 4096, 1}, {"NT gen_fwd 4864x30522x512", 0, 1, 4864, 30522, 512, 1},
+      {"NT ragged 1000x3001x520", 0, 1, 1000, 3001, 520, 1},
+      {"NN gen_dx 4864x512x30522 split 6", 0, 0, 4864, 512, 30522, 6}, {"NN ragged 700x500x5000 split 3", 0, 0, 700, 500, 5000, 3},
+      {"TN gen_dw 30522x512x4864", 1, 0, 30522, 512, 4864, 1}, {"TN ragged 3001x500x1000", 1, 0, 3001, 500, 1000, 1},
+      {"NTs dx-nt 4864x512x30528 split 6", 0, 1, 4864, 512, 30528, 6},
+  };
   hipStream_t st; hipStreamCreate(&st);
   for (const Shape& s : shapes) {
-    const int M = s.M, N = s.N, K = s.K;
-    const long ldc = (N + 7) / 8 * 8;
-    std::vector<uint16_t> ha((size_t)M * K), hb((size_t)N * K);
-    uint32_t seed = 12345u;
-    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& v : ha) v = f2bf_host(rnd());
-    for (auto& v : hb) v = f2bf_host(rnd() * 0.05f);
-    std::vector<float> hbias(N);
-    for (auto& v : hbias) v = rnd();
-    uint16_t *dA, *dB, *dC0, *dC1; float* dbias;
-    hipMalloc(&dA, ha.size() * 2); hipMalloc(&dB, hb.size() * 2 + 4096); hipMalloc(&dC0, (size_t)M * ldc * 2); hipMalloc(&dC1, (size_t)M * ldc * 2);
-    hipMalloc(&dbias, N * 4);
-    hipMemcpy(dA, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
-    hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice);
-    G256P p; memset(&p, 0, sizeof(p));
-    p.A = dA; p.B = dB; p.lda = K; p.ldb = K; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
-    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + 255) / 256; p.split = 1; p.kt_per_split = (K + 63) / 64;
-    p.bias = dbias; p.order = 1;
-    struct Var { const char* name; std::function<void(uint16_t*)> run; };
-    std::vector<Var> vars;
-    vars.push_back({"shipped gemm256 (16x16x32)", [&](uint16_t* c) { G256P q = p; q.C = c; base_launch<0, 1, bf16_t>(q, st); }});
-    vars.push_back({"pipelined MF=32", [&](uint16_t* c) { G256P q = p; q.C = c; g32_launch<0, 1, bf16_t, 32, 0>(q, st); }});
-    vars.push_back({"pipelined MF=32 prio", [&](uint16_t* c) { G256P q = p; q.C = c; g32_launch<0, 1, bf16_t, 32, 1>(q, st); }});
-    vars.push_back({"drain DI=1 NDR=2", [&](uint16_t* c) { G256P q = p; q.C = c; g32d_launch<1, 2, 0>(q, st); }});
-    vars.push_back({"drain DI=2 NDR=4 prio", [&](uint16_t* c) { G256P q = p; q.C = c; g32d_launch<2, 4, 1>(q, st); }});
-    vars.push_back({"drain DI=2 NDR=4", [&](uint16_t* c) { G256P q = p; q.C = c; g32d_launch<2, 4, 0>(q, st); }});
-    vars.push_back({"drain DI=0 (direct stores)", [&](uint16_t* c) { G256P q = p; q.C = c; g32d_launch<0, 1, 0>(q, st); }});
-    vars.push_back({"ablate: shipped, no epilogue", [&](uint16_t* c) { G256P q = p; q.C = c; q.dbg = 4; base_launch<0, 1, bf16_t>(q, st); }});
-    vars.push_back({"ablate: MF=32 no epilogue", [&](uint16_t* c) { G256P q = p; q.C = c; g32_launch<0, 1, bf16_t, 32, 4>(q, st); }});
-    // ---- correctness: every variant against a host fp64 reference on sampled rows / columns, and against the shipped kernel everywhere
-    hipMemset(dC0, 0, (size_t)M * ldc * 2);
-    vars[0].run(dC0); hipStreamSynchronize(st);
-    std::vector<uint16_t> c0((size_t)M * ldc), c1((size_t)M * ldc);
-    hipMemcpy(c0.data(), dC0, c0.size() * 2, hipMemcpyDeviceToHost);
-    for (size_t v = 0; v < 7; v++) {
-      hipMemset(dC1, 0xff, (size_t)M * ldc * 2);
-      vars[v].run(dC1); hipStreamSynchronize(st);
-      hipError_t e = hipGetLastError();
-      hipMemcpy(c1.data(), dC1, c1.size() * 2, hipMemcpyDeviceToHost);
-      double maxd = 0, maxref = 0; long nbad = 0;
-      for (int r = 0; r < M; r++)
-        for (int c = 0; c < N; c++) {
-          const double a = bf2f_host(c0[(size_t)r * ldc + c]), b = bf2f_host(c1[(size_t)r * ldc + c]);
-          const double d = fabs(a - b);
-          if (!(d <= 0.02 * (1.0 + fabs(a)))) nbad++;
-          if (d > maxd) maxd = d;
-          if (fabs(a) > maxref) maxref = fabs(a);
-        }
-      // host reference on a lattice
-      double maxe = 0;
-      for (int r = 0; r < M; r += 397)
-        for (int c = 0; c < N; c += 211) {
-          double acc = hbias[c];
-          for (int k = 0; k < K; k++) acc += (double)bf2f_host(ha[(size_t)r * K + k]) * bf2f_host(hb[(size_t)c * K + k]);
-          const double d = fabs(acc - bf2f_host(c1[(size_t)r * ldc + c])) / (1.0 + fabs(acc));
-          if (d > maxe) maxe = d;
-        }
-      printf("[%s] %-28s err=%d  vs shipped: max|d| %.4g (max|ref| %.3g) bad %ld   vs fp64 lattice: max rel %.4g\n", s.name, vars[v].name, (int)e,
-             maxd, maxref, nbad, maxe);
-    }
-    // ---- timing: interleaved rounds
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int r = 0; r < rounds; r++)
-      for (size_t v = 0; v < vars.size(); v++) {
-        for (int i = 0; i < 3; i++) vars[v].run(dC1);
-        hipEventRecord(e0, st);
-        for (int i = 0; i < iters; i++) vars[v].run(dC1);
-        hipEventRecord(e1, st); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double us = ms * 1e3 / iters;
-        printf("[%s] round %d %-28s %8.1f us  %7.1f TF\n", s.name, r, vars[v].name, us, 2.0 * M * N * K / us / 1e6);
-      }
-    hipFree(dA); hipFree(dB); hipFree(dC0); hipFree(dC1); hipFree(dbias);
-    fflush(stdout);
+    if (only[0] && !strstr(s.name, only)) continue;
+    if (s.ta == 0 && s.tb == 1 && s.split == 1) run_shape<0, 1, bf16_t>(s, st, iters, rounds);
+    else if (s.ta == 0 && s.tb == 1) run_shape<0, 1, float>(s, st, iters, rounds);
+    else if (s.ta == 0 && s.tb == 0) run_shape<0, 0, float>(s, st, iters, rounds);
+    else run_shape<1, 0, float>(s, st, iters, rounds);
   }
   return 0;
 }

@@ -362,7 +362,10 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   }
   if (form == 1) {             // NT: vocabulary projection forward (bf16 out, bias)
     if (!(mask & 1) || d->out_dtype != VCT_BF16 || d->bias_grad || d->split_k > 1) return VCT_OK;
-    if (d->M < 2048 || d->N < 8192 || (d->K % 8) || (d->ldc % 8) || ((uintptr_t)d->C & 15)) return VCT_OK;
+    // vocabulary-wide outputs, or any product of >= 240 tiles with >= 16 K stages (one round of persistent workgroups at least; 4096^3:
+    // 1190-1250 TF here against 960 on the 128x128 kernel) -- the layer products (<= 152 tiles of 256x256) stay where they are
+    const bool wide = d->N >= 8192, big = tiles >= 240 && nkt >= 16;
+    if (d->M < 2048 || !(wide || big) || (d->K % 8) || (d->ldc % 8) || ((uintptr_t)d->C & 15)) return VCT_OK;
     const int rc = g256_launch<0, 1, bf16_t>(p, st);
     if (rc == VCT_OK) *used = true;
     return rc;

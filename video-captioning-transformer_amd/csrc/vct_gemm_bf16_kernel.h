@@ -263,17 +263,22 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
 
   f32x4 acc[TM][TN];
-  f32x4 accb[TM];
+  // bias gradient = row sums of op(A): the WGN waves of a row group hold the same A fragments, so wave wn takes the tile rows
+  // i == wn (mod WGN).  (Rounds 1-5: the wn == 0 wave took all TM rows -- TM extra MFMAs per k-step on one wave of four, +50 % on its
+  // matrix-pipe work, and the tile, i.e. every tile of the first tile column, waited for it.)  Same MFMA sequence per row: same bits.
+  constexpr int TMB = (TM + WGN - 1) / WGN;
+  f32x4 accb[TMB];
+#pragma unroll
+  for (int u = 0; u < TMB; u++) accb[u] = f32x4{0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < TM; i++) {
-    accb[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
   }
   // the bias gradient only exists for the weight-gradient form (dW = dY^T X, fp32 out): everywhere else its accumulators
   // and its branch are compiled out (16 VGPRs back, one basic block per K tile)
   constexpr bool BG = (TA == 1 && TB == 0 && sizeof(TO) == 4);
-  const bool do_bias_grad = BG && (p.bias_grad != nullptr) && (tile_n == 0) && (wn == 0);
+  const bool do_bias_grad = BG && (p.bias_grad != nullptr) && (tile_n == 0);
   const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
@@ -323,10 +328,13 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
     }
     if constexpr (BG) {
       if (do_bias_grad) {
+        static_for<TM>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if (wn == i % WGN) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-          for (int i = 0; i < TM; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], ones, accb[i], 0, 0, 0);
+            for (int ks = 0; ks < KS; ks++) accb[i / WGN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], ones, accb[i / WGN], 0, 0, 0);
+          }
+        });
       }
     }
   };
@@ -381,13 +389,14 @@ __device__ __forceinline__ void gemm_bf16_v2_body(const GemmP& p, const int bid,
   if (do_bias_grad && c16 == 0) {
     float* bg = p.partial != nullptr ? p.bias_partial + (size_t)zid * p.M : p.bias_grad;
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+    for (int u = 0; u < TMB; u++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
+        const int i = wn + u * WGN;
         const int row = m0 + wm * WM + i * 16 + g4 + r;
-        if (row < p.M) {
-          if (p.counters != nullptr) coherent_store1(bg + row, accb[i][r]);
-          else bg[row] = accb[i][r];
+        if (i < TM && row < p.M) {
+          if (p.counters != nullptr) coherent_store1(bg + row, accb[u][r]);
+          else bg[row] = accb[u][r];
         }
       }
   }
