@@ -39,7 +39,10 @@ namespace vct {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ int kc32_swz(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int mc32_swz(int krow) { return ((krow & 3) << 1) | ((krow >> 2) & 1) | (krow & 8); }
+// M/N-contiguous image: the 64-byte unit u of k-row r sits at u ^ (r & 3) (units = pairs of 32-byte blocks): four lanes of a DMA
+// instruction still fetch 64 contiguous bytes, and the 32 lanes of one LDS cycle of a transpose read (four k-rows x one unit) hit four
+// distinct units mod 4 = all 64 banks
+__device__ __forceinline__ int mc32_swz(int krow) { return krow & 3; }
 
 // ragged last K stage: predicated 16-byte loads (zero fill beyond K / beyond the operand's rows) into the swizzled image
 template <bool MC, int NT>
@@ -69,7 +72,7 @@ __device__ __forceinline__ void tail_tile32(unsigned char* img, const bf16_t* __
       const int col = p * 8;
       const int gk = k0 + krow, gr = r0 + col;
       if (gk < K && gr < r_ext) val = *reinterpret_cast<const V16b*>(base + (long)gk * ld + gr);
-      *reinterpret_cast<V16b*>(img + krow * 512 + ((((p >> 1) ^ mc32_swz(krow)) << 1) | (p & 1)) * 16) = val;
+      *reinterpret_cast<V16b*>(img + krow * 512 + ((((p >> 2) ^ mc32_swz(krow)) << 2) | (p & 3)) * 16) = val;
     }
   }
 }
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         voff[q] = (min(r0 + row, ext - 1) * ld + c * 8) * 2;
       } else {
         const int krow = ci * 2 + (l >> 5), pp = l & 31;
-        const int col = ((((pp >> 1) ^ mc32_swz(krow)) << 1) | (pp & 1)) * 8;
+        const int col = ((((pp >> 2) ^ mc32_swz(krow)) << 2) | (pp & 3)) * 8;
         const int rlim = ((ext + 7) & ~7) - 8;                     // last fully readable vector (ld covers the rounded-up extent)
         voff[q] = (krow * ld + min(r0 + col, rlim)) * 2;
       }
@@ -163,15 +166,15 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
   int offA, offA2 = 0, offB, offB2 = 0;
   if constexpr (!A_MC) { const int r = wm * WM + rl; offA = r * 128 + ((hl ^ kc32_swz(r)) << 4); }
   else {
-    const int kr = hl * 8 + (i16 >> 2), blk = wm * 8 + g16;
-    offA = kr * 512 + ((blk ^ mc32_swz(kr)) << 5) + (i16 & 3) * 8;
-    offA2 = (kr + 4) * 512 + ((blk ^ mc32_swz(kr + 4)) << 5) + (i16 & 3) * 8;
+    const int kr = hl * 8 + (i16 >> 2), unit = wm * 4;
+    offA = kr * 512 + ((unit ^ mc32_swz(kr)) << 6) + g16 * 32 + (i16 & 3) * 8;
+    offA2 = offA + 4 * 512;
   }
   if constexpr (!B_MC) { const int r = wn * 64 + rl; offB = A_BYTES + r * 128 + ((hl ^ kc32_swz(r)) << 4); }
   else {
-    const int kr = hl * 8 + (i16 >> 2), blk = wn * 4 + g16;
-    offB = A_BYTES + kr * 512 + ((blk ^ mc32_swz(kr)) << 5) + (i16 & 3) * 8;
-    offB2 = A_BYTES + (kr + 4) * 512 + ((blk ^ mc32_swz(kr + 4)) << 5) + (i16 & 3) * 8;
+    const int kr = hl * 8 + (i16 >> 2), unit = wn * 2;
+    offB = A_BYTES + kr * 512 + ((unit ^ mc32_swz(kr)) << 6) + g16 * 32 + (i16 & 3) * 8;
+    offB2 = offB + 4 * 512;
   }
   bf16x8 fa[2][TM], fb[2][TN];
   auto read_one = [&](auto MCT, const unsigned char* sb, int o1, int o2, int step, int t) -> bf16x8 {
