@@ -19,7 +19,6 @@ void replay_note_error(int) {}
 }  // namespace vct
 
 
-#include "g32_kernel.h"
 #include "g32_kernel_v1.h"
 using namespace vct;
 

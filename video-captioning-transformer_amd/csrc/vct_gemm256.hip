@@ -280,7 +280,18 @@ int persistent_grid(hipStream_t st) {
   return grid;
 }
 
+}  // namespace vct
+#include "vct_gemm32_kernel.h"      // g32_kernel: the same persistent tile with a software-pipelined K loop on 32x32x16 (round 6)
+namespace vct {
+
 template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hipStream_t st) {
+  // VCT_GEMM32: which forms run on the pipelined kernel (1 = NT, 2 = NN, 4 = TN, 8 = NT split over K).  Default 2: the NN form (the
+  // vocabulary dX, 186-195 -> 160-165 us alone); the NT forms measure equal alone and slower in the step, the TN form is not in the step
+  // (DESIGN.md section 4, round 6).  gemm256_kernel takes what the pipelined kernel does not (fewer than two full K stages per work item).
+  static const char* env32 = getenv("VCT_GEMM32");
+  const int mask32 = env32 != nullptr ? atoi(env32) : 2;
+  constexpr int form_bit = (TA == 1) ? 4 : (TB == 0 ? 2 : (sizeof(TO) == 4 ? 8 : 1));
+  if ((mask32 & form_bit) && p.dbg == 0 && g32_eligible(p, TA == 1, TB == 0)) return g32_launch<TA, TB, TO, 0>(p, st);
   static vct::DynLdsOptIn optin;
   if (hipError_t e = optin.ensure((const void*)gemm256_kernel<TA, TB, TO>, G256_LDS); e != hipSuccess) return (int)e;
   vct::launch(gemm256_kernel<TA, TB, TO>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);

@@ -1,4 +1,3 @@
-// DEV PROBE, NOT PART OF THE LIBRARY (round 6; measured and rejected IN THE STEP).
 // Persistent 256x256-tile bf16 GEMM, second generation: gemm256_kernel's structure (vct_gemm256.hip: one workgroup per CU
 // walking a flat stream of (work item, K stage) steps, two 64-deep stages of 64 KB in LDS, 8 waves as 2 x 4, accumulators transposed
 // per MFMA tile) with a K loop that is software-pipelined at k-step granularity on v_mfma_f32_32x32x16_bf16.
@@ -32,7 +31,7 @@
 // Measured against gemm256_kernel, same process, same data (tools/g32_probe.hip): NT 4096^3 1190-1250 -> 1250-1300 TF, vocabulary
 // projection 171-177 -> 161-169 us; bit-identical outputs.
 #pragma once
-// (included by tools/g32_probe.hip behind vct_gemm256.hip, which defines G256P, G256_STAGE, persistent_grid ...)
+#include "vct_gemm_bf16_kernel.h"      // (included by vct_gemm256.hip, which defines G256P, G256_STAGE, persistent_grid ... in front of it)
 
 namespace vct {
 
@@ -176,13 +175,33 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     offB = A_BYTES + kr * 512 + ((unit ^ mc32_swz(kr)) << 6) + g16 * 32 + (i16 & 3) * 8;
     offB2 = offB + 4 * 512;
   }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   bf16x8 fa[2][TM], fb[2][TN];
+  // the asm transpose reads are not tracked by hipcc's lgkmcnt bookkeeping: before a fragment set is consumed, wait for every LDS read in
+  // flight and tie the wait to the registers (a register-only MFMA may otherwise be hoisted above it)
+  auto wait_frags0 = [&]() {
+    if constexpr (A_MC || B_MC)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
+  };
+  auto wait_frags1 = [&]() {
+    if constexpr (A_MC || B_MC)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory");
+  };
   auto read_one = [&](auto MCT, const unsigned char* sb, int o1, int o2, int step, int t) -> bf16x8 {
     if constexpr (!decltype(MCT)::value) {
       return *reinterpret_cast<const bf16x8*>(sb + (o1 ^ (step << 5)) + t * T * 128);
     } else {
-      const s16x4 lo = lds_tr16(reinterpret_cast<const bf16_t*>(sb + (o1 ^ (t << 6)) + step * 8192));
-      const s16x4 hi = lds_tr16(reinterpret_cast<const bf16_t*>(sb + (o2 ^ (t << 6)) + step * 8192));
+      // INLINE ASM, on purpose: behind a pending LDS-DMA hipcc puts `s_waitcnt vmcnt(0)` in front of the transpose-read INTRINSIC (it
+      // does not for plain ds_read_b128 loads) -- every k-step then waits for the DMA of the NEXT stage to land, the DMA never overlaps
+      // the MFMAs, and the NN / TN forms pay the whole DMA time on top of the compute loop (+55-78 us on the vocabulary products, in
+      // gemm256_kernel too).  The asm is invisible to that pass; completion is ordered by wait_frags() below.
+      const uint32_t ad = (uint32_t)(sb - lds) + lds_base + (uint32_t)(o1 ^ (t << 6));
+      s16x4 lo, hi;
+      if (step == 0) asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+      else if (step == 1) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:8192\n\tds_read_b64_tr_b16 %1, %2 offset:10240" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+      else if (step == 2) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:16384\n\tds_read_b64_tr_b16 %1, %2 offset:18432" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+      else asm volatile("ds_read_b64_tr_b16 %0, %2 offset:24576\n\tds_read_b64_tr_b16 %1, %2 offset:26624" : "=&v"(lo), "=&v"(hi) : "v"(ad) : "memory");
+      (void)o2;
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       return __builtin_bit_cast(bf16x8, v);
     }
@@ -285,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
           if (pend_kt >= 0) static_for<3>([&](auto U) { dma(std::integral_constant<int, 2 + j * 3 + decltype(U)::value>{}, nb, pend_kt); });
           if constexpr (j == 1) pend_kt = -1;
         }
+        if constexpr ((j & 1) == 0) wait_frags0(); else wait_frags1();
         read_frags(std::integral_constant<int, (j + 1) & 1>{}, sb, j + 1);
         mfma_step(std::integral_constant<int, j & 1>{});
         static_for<NMF>([&](auto I) {
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
       const bool nx2_dma = nx2 && kt2 < kt_full;
       if (kt == k_hi - 2 && have_next) set_voff(m1, n1);            // (every DMA from here on belongs to the next item)
       if (nx2 && !nx2_dma) tail_stage(sb, m2, n2, kt2);
+      wait_frags1();
       if (nx1) read_frags(std::integral_constant<int, 0>{}, nb, 0);
       static_for<TM>([&](auto I) {
         constexpr int i = decltype(I)::value;
