@@ -335,9 +335,11 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         constexpr int i = decltype(I)::value;
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
-        if constexpr (i == 1 || i == 3) { if (nx2_dma) dma(std::integral_constant<int, i / 2>{}, sb, kt2); }
+        if constexpr (VAR & 2) {                                    // (A/B: the whole DMA group in this k-step, two pieces per tile row)
+          if (nx2_dma) static_for<2>([&](auto U) { dma(std::integral_constant<int, i * 2 + decltype(U)::value>{}, sb, kt2); });
+        } else if constexpr (i == 1 || i == 3) { if (nx2_dma) dma(std::integral_constant<int, i / 2>{}, sb, kt2); }
       });
-      if (nx2_dma) pend_kt = kt2;
+      if constexpr (!(VAR & 2)) { if (nx2_dma) pend_kt = kt2; }
       if (do_bg) bias_grad_step(std::integral_constant<int, 1>{});
       buf ^= 1;
     }

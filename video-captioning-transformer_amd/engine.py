@@ -453,6 +453,21 @@ class _StackBase:
             else:
                 self._on_side(lambda ws: ops.gemm_grouped(items, ws))
 
+    def flush_dw_across(self, other):
+        """Issue the queued weight-gradient group on the stream `other` (behind everything enqueued so far on the current one) instead
+        of in line on the current stream: the encoder backward runs as ONE serial chain on the side stream, and a layer's group in
+        the middle of that chain (72 us alone, 187 us beside the vocabulary dW) delays every kernel behind it, while the main
+        stream idles at the end of the step (profiles/r05_step_timeline_list.txt).  The group only needs this layer's dY / X."""
+        if not self._dw_pending:
+            return
+        cur = torch.cuda.current_stream()
+        if other is None or other == cur or not (self.overlap_dw and self.dev.type == "cuda"):
+            return self.flush_dw()
+        items, self._dw_pending = self._dw_pending, []
+        ops.stream_wait(other, cur)
+        with torch.cuda.stream(other):
+            ops.gemm_grouped(items, self.gemm_ws() if other != self.ps.ctx.side else self.ps.ctx.side_ws)
+
     def bucket_on_side(self, bucket_ready, *args):
         """Hand a finished gradient bucket to `bucket_ready` WITHOUT stalling the dX chain: the hook runs with the
         side stream current, after that stream has been ordered behind everything enqueued so far on the main
@@ -941,13 +956,18 @@ class EncoderEngine(_StackBase):
             ds1, da = self._ln_bwd(b, tag + "n1.", lp + "norm1.", dx1, b.t[tag + "sa.a"], x, site + 2)
             dx = self._attn_block_bwd(b, tag + "sa.", lp + "self_attn.", da, x, x, B, Te, Te, False, kpm, site + 1, True, ds1)
             if l > 0:
-                self.flush_dw()           # this layer's weight gradients: one grouped launch beside the next layer
+                if bucket_ready is None and self.enc_dw_main and getattr(self, "main_stream", None) is not None:
+                    self.flush_dw_across(self.main_stream)      # behind the main stream's tail (vocabulary dW, optimizer pass)
+                else:
+                    self.flush_dw()       # this layer's weight gradients: one grouped launch beside the next layer
             if bucket_ready is not None and l > 0:
                 self.flush_ln_grads(b)
                 self.bucket_on_side(bucket_ready, "enc_layer", l)
         du = ops.enc_frontend_bwd(dx, b.get("du", (B * T, self.cfg["d"]), self.dt), B, T)
         self.dw_gemm(du, b.t["x_in"], self.G("unify.0.weight"), bias_grad=self.G("unify.0.bias"))
         self.flush_ln_grads(b)
+        if bucket_ready is None and self.enc_dw_main >= 2 and getattr(self, "main_stream", None) is not None:
+            self.flush_dw_across(self.main_stream)       # (A/B: the bottom layer's group too)
         self.join_side()
         if bucket_ready is not None:
             bucket_ready("enc_layer", 0)
@@ -1461,7 +1481,10 @@ def _decoder_decode_step_any(self, st: DecodeState, t: int, end_id: int):
 # stream's slack at the end of the step.  (Rebuilt in front of the layer stack at every step it cost the forward more than the dX
 # gained.)  Measured in the step (same box): the dX bracket drops 0.218 -> 0.181 ms and the Adam bracket grows by the 40 us of the
 # transpose; step 2.44-2.45 ms either way (the chip is work-bound: the side stream fills whatever the main stream leaves) -> off.
-DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "1") != "0"
+# (round 6: the NN form on the pipelined 256x256 kernel runs at the NT form's speed -- 0.183 ms both -- so the transposed shadow W_g^T
+# (a 39 us transpose + the 2-D optimizer pass per step behind a gradient exchange) is no longer kept by default: exchange path -0.8 %)
+DecoderEngine.gen_dx_nt = os.environ.get("VCT_GEN_DX_NT", "0") != "0"
+EncoderEngine.enc_dw_main = int(os.environ.get("VCT_ENC_DW_MAIN", "1"))
 DecoderEngine.early_gen_dw = os.environ.get("VCT_GEN_DW_EARLY", "0") == "1"
 # bit 0 / bit 1: the bottom decoder layer's cross-attention + feed-forward / self-attention weight gradients on the MAIN stream (A/B)
 DecoderEngine.l0_dw_main = int(os.environ.get("VCT_L0_DW_MAIN", "3"))

@@ -213,8 +213,10 @@ class MMT4Caption(nn.Module):
                     return
                 side = dec.ensure_side()
                 ops.sync_wait(dmem_point, side)                   # d(memory) final (its last accumulate is on `side` itself)
+                enc.main_stream = torch.cuda.current_stream()     # (EncoderEngine.enc_dw_main: upper layers' weight-gradient groups go there)
                 with torch.cuda.stream(side):
                     enc.backward(dmem, hook)
+                enc.main_stream = None
 
             def on_dmem(dmem, dmem_point):
                 if join:
