@@ -450,8 +450,9 @@ def main():
             "gen_fwd": ("mfma", fl["gen"], "gemm256_kernel<0, 1, bf16>",
                         "generator GEMM fwd 4864x30522x512 (gemm256_kernel NT: persistent 256x256 tiles, 8 waves, LDS-DMA double buffer)"),
             "gen_dx": ("mfma", fl["gen"], "gemm256_kernel<0, 1, float>" if getattr(model.cap_decoder._engine(), "_wgt", None) is not None
-                       else "gemm256_kernel<0, 0, float>",
-                       "generator dX GEMM 4864x512x30522 (gemm256_kernel, split over K, + fixed-order reduce)"),
+                       else "g32_kernel<0, 0, float",
+                       "generator dX GEMM 4864x512x30522 (g32_kernel NN: persistent 256x256 tiles, software-pipelined K loop on 32x32x16, "
+                       "split over K, + fixed-order reduce)"),
             "gen_dw": ("mfma", fl["gen"], "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>",
                        "generator dW GEMM 30522x512x4864 (TN, fp32 out" + (", torch.optim.Adam's step on W_g in its epilogue" if fused_adam else "")
                        + "; runs beside the encoder backward)"),
@@ -475,7 +476,7 @@ def main():
                 ach, pk, unit = work / (ms_ * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             return bound, ach, pk, unit
         traffic, traffic_src = None, None
-        for name in ("r05_roofline_traffic.json", "r04_roofline_traffic.json"):
+        for name in ("r06_roofline_traffic.json", "r05_roofline_traffic.json", "r04_roofline_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 ent = tj[dom]

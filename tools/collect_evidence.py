@@ -63,7 +63,7 @@ def opt(name, alg, *prefixes):
 
 
 red = rows[find("splitk_reduce_kernel<bf16>")]
-dx = ent(find("gemm256_kernel<0, 0, float>", "gemm256_kernel<0, 1, float>"), "gen_dx", 333000000)
+dx = ent(find("g32_kernel<0, 0, float", "gemm256_kernel<0, 0, float>", "gemm256_kernel<0, 1, float>"), "gen_dx", 333000000)
 dx["reduce_fetch_bytes"], dx["reduce_write_bytes"] = kb(red["FETCH_SIZE"] * 2), kb(red["WRITE_SIZE"])
 dx["hbm_bytes"] += dx["reduce_fetch_bytes"] + dx["reduce_write_bytes"]
 ls = rows[find("sce_loss_kernel<bf16")]
