@@ -250,6 +250,47 @@ def test_plain_backward_beside_a_fusing_trainer_still_produces_gradients():
     assert float(g.abs().max()) > 0 and bool(torch.isfinite(g).all())
 
 
+@pytest.mark.parametrize("executor", ["eager", "list"])
+def test_weight_gradients_of_a_fused_step_are_flagged_stale_or_kept(executor):
+    """The reference leaves valid .grad after backward (train.py:125).  The single-GPU bf16 trainer consumes the weight-matrix
+    gradients inside the weight-gradient GEMMs: model.grads_valid is False after such a step and check_grads_valid() raises;
+    CaptionTrainer(keep_weight_grads=True) stores them as well -- same parameters bit for bit, and the stored gradients are the
+    gradients a plain backward of the same batch on the same weights produces."""
+    from vct_amd.trainer import CaptionTrainer, FusedAdam
+    res = {}
+    for keep in (False, True):
+        m = _model(dropout=0.0)
+        opt = FusedAdam(m, lr=1e-3)
+        tr = CaptionTrainer(m, opt, launch_list=executor == "list", keep_weight_grads=keep)
+        assert m.grads_valid is True
+        before = m.flat_params.clone()
+        tr.step(*_batch(100))
+        torch.cuda.synchronize()
+        assert m.grads_valid is keep
+        if not keep:
+            with pytest.raises(RuntimeError):
+                m.check_grads_valid()
+        else:
+            m.check_grads_valid()
+            g_step = m.flat_grads.clone()
+            # the same gradients from a plain backward at the weights the step started from
+            m2 = _model(dropout=0.0)
+            m2.flat_params.copy_(before); m2._ps.refresh_shadow(force=True)
+            f, k, i = _batch(100)
+            m2.zero_grad(set_to_none=False)
+            m2([f], [k], i).backward()
+            torch.cuda.synchronize()
+            assert m2.grads_valid is True
+            for name in ("cap_decoder.generator.weight", "cap_decoder.decoder.layers.0.linear1.weight",
+                         "video_encoder.transformer_encoder.layers.1.self_attn.in_proj_weight", "cap_decoder.generator.bias"):
+                assert torch.equal(m._ps.g[name], m2._ps.g[name]), name
+            assert float(g_step.abs().max()) > 0
+        tr.step(*_batch(101))
+        torch.cuda.synchronize()
+        res[keep] = m.flat_params.clone()
+    assert torch.equal(res[False], res[True])
+
+
 def test_adopted_input_buffers_skip_the_staging_copies_and_give_the_same_step():
     """CaptionTrainer.adopt_inputs: a producer that writes its batches into the executor's own static buffers; same losses and
     parameters as passing fresh tensors (which step() copies into those buffers)."""

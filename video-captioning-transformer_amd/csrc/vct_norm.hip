@@ -318,36 +318,40 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(int nws, int d, 
 // batched form: one launch finalizes the dgamma/dbeta of several LayerNorms (table of 4 x int64 per
 // entry: partials pointer, dgamma pointer, dbeta pointer, number of partial rows)
 __global__ __launch_bounds__(256) void ln_param_finalize_batched_kernel(const int64_t* __restrict__ table, int d) {
-  __shared__ float red[16][17];
+  // a workgroup owns 32 consecutive columns of the [rows][2 d] partial rows: eight lanes x 16 bytes = one whole 128-byte line per row and
+  // load (round 6; the former 16-column x 4-byte form fetched half lines: 21 us for the decoder's 34 MB = 1.6 TB/s on the critical path)
+  __shared__ float red[32][33];
   const int64_t* ent = table + (size_t)blockIdx.y * 4;
   const float* ws = reinterpret_cast<const float*>(ent[0]);
   float* dgamma = reinterpret_cast<float*>(ent[1]);
   float* dbeta = reinterpret_cast<float*>(ent[2]);
   const int nws = (int)ent[3];
-  const int cx = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cx;
-  float s = 0.0f;
+  const int cx = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + cx * 4;                 // first of this lane's four columns (d % 4 == 0: never straddles gamma | beta)
+  float4 s = {0.0f, 0.0f, 0.0f, 0.0f};
   if (c < 2 * d) {
-    const int which = c / d, col = c % d;
-    // eight loads in flight per thread (the adds keep their order): the ~38 partial rows of a thread were a chain of L2 round trips
-    const float* src = ws + (size_t)which * d + col;
+    const float* src = ws + c;
     int r = rg;
-    for (; r + 7 * 16 < nws; r += 8 * 16) {
-      float v[8];
+    for (; r + 7 * 32 < nws; r += 8 * 32) {               // eight loads in flight per thread (the adds keep their order)
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = src[(size_t)(r + u * 16) * 2 * d];
+      for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(r + u * 32) * 2 * d);
 #pragma unroll
-      for (int u = 0; u < 8; u++) s += v[u];
+      for (int u = 0; u < 8; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
-    for (; r < nws; r += 16) s += src[(size_t)r * 2 * d];
+    for (; r < nws; r += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * 2 * d);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  red[rg][cx] = s;
+  red[rg][cx * 4 + 0] = s.x; red[rg][cx * 4 + 1] = s.y; red[rg][cx * 4 + 2] = s.z; red[rg][cx * 4 + 3] = s.w;
   __syncthreads();
-  if (rg == 0 && c < 2 * d) {
+  const int col = blockIdx.x * 32 + (int)threadIdx.x;
+  if (threadIdx.x < 32 && col < 2 * d) {
     float t = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) t += red[k][cx];
-    (c < d ? dgamma : dbeta)[c % d] = t;
+    for (int k = 0; k < 32; k++) t += red[k][threadIdx.x];
+    (col < d ? dgamma : dbeta)[col % d] = t;
   }
 }
 
@@ -456,7 +460,7 @@ extern "C" int vct_add_ln_ln_bwd(int dtype, int M, int d, const void* dy2, const
 extern "C" int vct_ln_param_finalize_batched(const int64_t* table_dev, int n_entries, int d, void* stream) {
   if (!table_dev) return VCT_E_ARG;
   if (n_entries <= 0 || d <= 0) return VCT_E_SHAPE;
-  vct::launch(ln_param_finalize_batched_kernel, dim3((2 * d + 15) / 16, n_entries), dim3(256), 0, (hipStream_t)stream,
+  vct::launch(ln_param_finalize_batched_kernel, dim3((2 * d + 31) / 32, n_entries), dim3(256), 0, (hipStream_t)stream,
                      table_dev, d);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
