@@ -453,8 +453,9 @@ def main():
                        else "g32_kernel<0, 0, float",
                        "generator dX GEMM 4864x512x30522 (g32_kernel NN: persistent 256x256 tiles, software-pipelined K loop on 32x32x16, "
                        "split over K, + fixed-order reduce)"),
-            "gen_dw": ("mfma", fl["gen"], "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>",
-                       "generator dW GEMM 30522x512x4864 (TN, fp32 out" + (", torch.optim.Adam's step on W_g in its epilogue" if fused_adam else "")
+            "gen_dw": ("mfma", fl["gen"], "g32_kernel<1, 0, float",
+                       "generator dW GEMM 30522x512x4864 (g32_kernel TN: persistent 256x256 tiles, software-pipelined K loop, transpose reads of "
+                       "both operands, bias gradient balanced over the waves, fp32 out" + (", torch.optim.Adam's step on W_g in its epilogue" if fused_adam else "")
                        + "; runs beside the encoder backward)"),
             "ss_enc": ("mfma", fl["enc_stack"], "layer_ss_fwd_kernel<false, 1>",
                        "sample-stationary ENCODER stack forward, one launch: unify Linear + mean token + temporal encoding + 2 layers + final norm"),

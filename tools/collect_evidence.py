@@ -74,7 +74,7 @@ out = {"_source": f"FINAL code of round {int(rnd[1:])}: rocprofv3 --pmc passes o
        "gen_fwd": ent(find("gemm256_kernel<0, 1, bf16>"), "gen_fwd", 333000000), "gen_dx": dx,
        # the vocabulary weight gradient WITH the optimizer epilogue: dlogits 297.0 MB + y 5.0 MB read, then per parameter (15,627,264)
        # p / m / v read and written + the bf16 shadow written = 26 B (no gradient store); without the epilogue it was 364.5 MB
-       "gen_dw": ent(find("gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 297000000 + 5000000 + 26 * 15627264),
+       "gen_dw": ent(find("g32_kernel<1, 0, float", "gemm_bf16_v2_kernel<float, 1, 0, 128, 128, 2, 2, 4>"), "gen_dw", 297000000 + 5000000 + 26 * 15627264),
        "sce_loss": ent(find("sce_loss_kernel<bf16"), "sce_loss", 593952768), "adam": ent(find("adam_ranges_kernel", "adam_kernel"), "adam", 0),
        **opt("adam2d", 0, "adam2d_kernel"), "embed_bwd": ent(find("embed_bwd_kernel<bf16>"), "embed_bwd", 4864 * (1024 + 2048)),
        # the sample-stationary stacks: every workgroup streams all of the stack's weights through its XCD's L2 (algorithmic = the

@@ -505,7 +505,7 @@ extern "C" int vct_gemm(const vct_gemm_desc* d, void* stream) {
     const int rcs = gemm_skinny_try(d, st, &used);
     if (rcs != VCT_OK || used) return rcs;
   }
-  if (!general_only) {
+  if (!general_only || (d->ta == 1 && d->tb == 0)) {       // (the pipelined 256 x 256 kernel carries the optimizer epilogue in its TN form)
     bool used = false;
     int rsplit = 1;
     const int rc256 = gemm256_try(d, st, &used, &rsplit);

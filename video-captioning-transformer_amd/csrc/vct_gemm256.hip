@@ -27,6 +27,7 @@
 // per-CU store issue rate (~14 B/clk): with one workgroup per CU nothing overlaps it, de-phasing the workgroups or draining
 // the stores behind a counted vmcnt changes nothing.
 #include "vct_gemm_bf16_kernel.h"
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 
@@ -44,6 +45,7 @@ struct G256P {
   int order;                    // tile order inside the flat work stream (see item())
   int zmajor;                   // split > 1: K split outermost (tiles that share the A rows of one K range are neighbours)
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
+  AdamEpiP adam;                // weight-gradient form on g32_kernel only (vct_gemm_adam); param == nullptr: off
 };
 
 constexpr int G256_BM = 256, G256_BN = 256;
@@ -284,14 +286,20 @@ int persistent_grid(hipStream_t st) {
 #include "vct_gemm32_kernel.h"      // g32_kernel: the same persistent tile with a software-pipelined K loop on 32x32x16 (round 6)
 namespace vct {
 
-template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hipStream_t st) {
-  // VCT_GEMM32: which forms run on the pipelined kernel (1 = NT, 2 = NN, 4 = TN, 8 = NT split over K).  Default 2: the NN form (the
-  // vocabulary dX, 186-195 -> 160-165 us alone); the NT forms measure equal alone and slower in the step, the TN form is not in the step
-  // (DESIGN.md section 4, round 6).  gemm256_kernel takes what the pipelined kernel does not (fewer than two full K stages per work item).
+// VCT_GEMM32: which forms run on the pipelined kernel (1 = NT, 2 = NN, 4 = TN, 8 = NT split over K).  Default 6: the vocabulary dX
+// (NN, 186-195 -> 157-165 us alone, 0.218 -> 0.182 ms in the step) and the vocabulary dW (TN, with the optimizer epilogue); the NT forms
+// measure equal alone and slower in the step.  gemm256_kernel takes what the pipelined kernel does not
+// (fewer than two full K stages per work item).
+static bool g32_takes(int form_bit) {
   static const char* env32 = getenv("VCT_GEMM32");
-  const int mask32 = env32 != nullptr ? atoi(env32) : 2;
+  const int mask32 = env32 != nullptr ? atoi(env32) : 6;
+  return (mask32 & form_bit) != 0;
+}
+
+template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hipStream_t st) {
   constexpr int form_bit = (TA == 1) ? 4 : (TB == 0 ? 2 : (sizeof(TO) == 4 ? 8 : 1));
-  if ((mask32 & form_bit) && p.dbg == 0 && g32_eligible(p, TA == 1, TB == 0)) return g32_launch<TA, TB, TO, 0>(p, st);
+  if (g32_takes(form_bit) && p.dbg == 0 && g32_eligible(p, TA == 1, TB == 0)) return g32_launch<TA, TB, TO, 0>(p, st);
+  if (p.adam.param != nullptr) return VCT_E_ARG;             // (gemm256_try never gets here: the round-5 kernel has no optimizer epilogue)
   static vct::DynLdsOptIn optin;
   if (hipError_t e = optin.ensure((const void*)gemm256_kernel<TA, TB, TO>, G256_LDS); e != hipSuccess) return (int)e;
   vct::launch(gemm256_kernel<TA, TB, TO>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
@@ -304,7 +312,7 @@ template <int TA, int TB, typename TO> static int g256_launch(const G256P& p, hi
 int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_split) {
   *used = false;
   *reduce_split = 1;
-  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN, 8 = NT split over K (narrow output).  Default 11 (NT, NN, NT split).
+  // VCT_GEMM256: 0 disables; else a mask 1 = NT, 2 = NN, 4 = TN, 8 = NT split over K (narrow output).  Default 15 (round 6: TN too).
   // With the DMA instructions spread between the MFMA groups (and their addresses no longer hoisted: no spills in any form) the same
   // box gives NT 184 vs 250, NN 223 vs 248, TN 182 vs 192 us against the 128x128 kernel; in the STEP the TN form (the weight gradient,
   // which runs beside the encoder backward on the other stream) makes things worse -- one workgroup per CU with 128 KB of LDS leaves
@@ -313,12 +321,13 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   // whose operands go through the LDS transpose read need twice the fragment reads and spill at 256 VGPRs; they stay available
   // (and tested) behind the mask.
   static const char* env = getenv("VCT_GEMM256");
-  const int mask = env != nullptr ? atoi(env) : 11;
+  const int mask = env != nullptr ? atoi(env) : 15;
   if (mask == 0 || d->dtype != VCT_BF16 || (d->reserved != 0 && d->reserved < 99)) return VCT_OK;
   if (d->act != VCT_ACT_NONE || d->preact || d->addend || d->dact_src || (d->seed && d->p_drop > 0.0f)) return VCT_OK;
   const int form = d->ta * 2 + d->tb;                         // 1 NT, 0 NN, 2 TN
   if (d->K < 256) return VCT_OK;
   G256P p;
+  memset(&p.adam, 0, sizeof(p.adam));
   p.A = reinterpret_cast<const bf16_t*>(d->A); p.B = reinterpret_cast<const bf16_t*>(d->B); p.C = d->C;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -384,6 +393,16 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   if (form == 2) {             // TN: weight gradient (fp32 out, bias gradient), one item per tile, no split
     if (!(mask & 4) || d->out_dtype != VCT_F32 || d->bias || d->split_k > 1) return VCT_OK;
     if (tiles < 192 || tiles > 256 || nkt < 32 || (d->ldc % 4) || ((uintptr_t)d->C & 15)) return VCT_OK;
+    memset(&p.adam, 0, sizeof(p.adam));
+    if (d->adam != nullptr) {
+      // optimizer epilogue (vct_gemm_adam): in the pipelined kernel only, whole 4-element chunks, no stream-order packed copy
+      // (the vocabulary weight has none); anything else stays with the 128 x 128 kernel
+      const vct_gemm_adam* a = d->adam;
+      if (!g32_takes(4) || (d->N % 4) || a->pk_stream != nullptr || !g32_eligible(p, true, true)) return VCT_OK;
+      p.adam.param = a->param; p.adam.m = a->exp_avg; p.adam.v = a->exp_avg_sq;
+      p.adam.shadow = reinterpret_cast<uint16_t*>(a->shadow); p.adam.ld_shadow = (long)a->ld_shadow;
+      p.adam.store_grad = a->store_grad; p.adam.hyper = a->hyper; p.adam.step = a->step;
+    }
     const int rc = g256_launch<1, 0, float>(p, st);
     if (rc == VCT_OK) *used = true;
     return rc;

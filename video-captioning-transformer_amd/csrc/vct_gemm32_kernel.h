@@ -18,18 +18,29 @@
 //   * LDS images (lane-linear as the DMA requires; the swizzle is applied to the SOURCE address and, identically, on the read):
 //       K-contiguous operand   [256 rows][64 k]: 16-byte chunk c of row r at c ^ ((r >> 1) & 7): lanes 0-31 of a 32-row fragment read
 //                              32 consecutive rows at ONE chunk -- conflict-free over ds_read_b128's 16-lane groups;
-//       M/N-contiguous operand [64 k][256 cols]: 32-byte block b of k-row r at b ^ f(r), f = rotate-left-1 of r's low three bits
-//                              (| r & 8): the 32 lanes of one LDS cycle of ds_read_b64_tr_b16 cover two adjacent blocks x four
-//                              consecutive k-rows = eight distinct block positions mod 8.  (gemm256_kernel's NN form: 24 % of its
+//       M/N-contiguous operand [64 k][256 cols]: 64-byte unit u of k-row r at u ^ (r & 3): four lanes of a DMA instruction still
+//                              fetch 64 contiguous bytes, and the 32 lanes of one LDS cycle of ds_read_b64_tr_b16 (four k-rows x
+//                              one unit) hit four distinct units mod 4 = all 64 banks.  (gemm256_kernel's NN form: 24 % of its
 //                              LDS cycles are bank conflicts, its r & 15 swizzle maps k-rows r and r + 8 onto the same banks.)
+//   * the transpose reads are INLINE ASM with a hand-placed s_waitcnt lgkmcnt(0) tied to the fragment registers: in front of the
+//     ds_read_tr16_b64 INTRINSIC hipcc emits s_waitcnt vmcnt(0) whenever an LDS-DMA is pending (it does not for ds_read_b128), i.e. in
+//     the NN / TN forms the DMA of stage s+1 never overlapped the MFMAs of stage s -- in gemm256_kernel as well, which is the larger
+//     half of what this kernel gains over it there (profiles/r06_g32_probe_asm_tr.txt);
 //   * the 64 DMA instructions of a stage are not issued in one burst: 2 per wave ride between the MFMAs of the last k-step, 3 + 3
 //     open k-steps 0 and 1 of the NEXT stage (their buffer is free from the barrier on and is read again only after the next one):
 //     issued together they queue behind the CU's vector-memory port (64 B/clk) and every wave sits in "issue" instead of in its MFMAs
 //     -- the NN form lost 63 us to that, more than the 39 us the whole DMA stream takes alone;
 //   * a ragged last K stage takes a zero-filling register path into the same images; the epilogue is gemm256_kernel's (row slab in
 //     the stage just consumed, whole-row stores), fp32 partials for the K-split forms.
-// Measured against gemm256_kernel, same process, same data (tools/g32_probe.hip): NT 4096^3 1190-1250 -> 1250-1300 TF, vocabulary
-// projection 171-177 -> 161-169 us; bit-identical outputs.
+//   * TN form (weight gradient): the bias gradient (column sums of A = ones-row MFMAs) is split over the four waves of a row -- wave
+//     wn takes k-step wn of every stage -- and reduced through the free stage buffer at the tile's end (one wave doing all of them
+//     was the tile's critical path); with p.adam set the fp32 read-out of the slab IS the optimizer step (vct_adam_core.h: p / m / v
+//     read and written, bf16 shadow written, the gradient itself stored only on request), two 16-byte chunks in flight per lane.
+// Measured against gemm256_kernel, same process, same data (tools/g32_probe.hip, profiles/r06_g32_probe_*.txt): NT 4096^3 1190-1250 ->
+// 1250-1300 TF; vocabulary products NT 171-177 -> 161-169 us alone but 0.170 -> 0.188 ms in the step (its burstier LDS traffic loses
+// beside the side stream's kernels: NT stays on gemm256_kernel), NN 218 -> 182 us and TN 333 -> 222 us IN the step (both adopted;
+// VCT_GEMM32 bit mask, default 6 = NN | TN).  Outputs are bit-identical to gemm256_kernel's for NT / NN (same accumulation order); the
+// TN form's bias gradient sums in a different (fixed) order.
 #pragma once
 #include "vct_gemm_bf16_kernel.h"      // (included by vct_gemm256.hip, which defines G256P, G256_STAGE, persistent_grid ... in front of it)
 
@@ -38,9 +49,7 @@ namespace vct {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ int kc32_swz(int row) { return (row >> 1) & 7; }
-// M/N-contiguous image: the 64-byte unit u of k-row r sits at u ^ (r & 3) (units = pairs of 32-byte blocks): four lanes of a DMA
-// instruction still fetch 64 contiguous bytes, and the 32 lanes of one LDS cycle of a transpose read (four k-rows x one unit) hit four
-// distinct units mod 4 = all 64 banks
+// M/N-contiguous image: the 64-byte unit u of k-row r sits at u ^ (r & 3) (header)
 __device__ __forceinline__ int mc32_swz(int krow) { return krow & 3; }
 
 // ragged last K stage: predicated 16-byte loads (zero fill beyond K / beyond the operand's rows) into the swizzled image
@@ -237,19 +246,23 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
   zero_acc();
   // bias of the lane's columns (groups of four consecutive columns, index j * 4 + q)
   constexpr int NBG = TN * 4;
-  f32x4 bj[NBG];
-  // bias gradient (weight-gradient form) = row sums of op(A): the four waves of a row group hold the same A fragments, wave wn sums
-  // tile row i == wn (16 VALU per k-step and wave; the round-5 kernel's wn == 0 waves did all four rows, 64 conversions + adds per
-  // k-step, and the other six waves waited for them at every stage barrier)
+  constexpr bool HAS_BIAS = (TA == 0 && TB == 1 && ES == 2);       // the plain NT form only (gemm256_try): 32 registers back elsewhere
+  f32x4 bj[HAS_BIAS ? NBG : 1];
+  // bias gradient (weight-gradient form) = row sums of op(A).  The four waves of a row group hold the same A fragments: wave wn sums the
+  // fragments of k-step j == wn of every stage (all four tile rows: static register indices -- a wave-uniform SELECT of the tile row
+  // makes hipcc park the fragments in scratch and wait vmcnt(0) per k-step, 580 us), the four partial sums meet in LDS at the tile's
+  // end in fixed order.  (gemm256_kernel: the wn == 0 wave did all of it, 64 VALU per k-step, and the other six waves waited for it
+  // at every stage barrier: the TN compute loop took 150 us with the bias gradient and 106 without.)
   float accb[BG ? TM : 1];
 #pragma unroll
   for (int i = 0; i < (BG ? TM : 1); i++) accb[i] = 0.0f;
   int n0 = 0;
   auto load_bias = [&]() {
+    if constexpr (!HAS_BIAS) return;
     int h = hl;
     asm volatile("" : "+v"(h));
 #pragma unroll
-    for (int g = 0; g < NBG; g++) {
+    for (int g = 0; g < (HAS_BIAS ? NBG : 1); g++) {
       const int col = n0 + wn * 64 + (g >> 2) * T + (g & 3) * 8 + h * 4;
       if (p.bias == nullptr || p.partial != nullptr) bj[g] = f32x4{0, 0, 0, 0};
       else if (col + 4 <= p.N) bj[g] = *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -273,6 +286,12 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     }
   };
 
+  bool adam_on = false;
+  AdamConsts hc = {};
+  if constexpr (BG && ES == 4) {
+    adam_on = p.adam.param != nullptr && p.partial == nullptr;
+    if (adam_on) hc = adam_consts_uniform(p.adam.hyper, p.adam.step);
+  }
   int w = w_begin + slot;
   int m0 = 0, z = 0, k_lo = 0, k_hi = 0;
   int buf = 0;
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     int m1 = 0, n1 = 0, z1 = 0, k1_lo = 0, k1_hi = 0;
     const bool have_next = w + nxw < w_end;
     if (have_next) item(w + nxw, m1, n1, z1, k1_lo, k1_hi);
-    const bool do_bg = BG && p.bias_grad != nullptr && n0 == 0 && wn == 0;
+    const bool do_bg = BG && p.bias_grad != nullptr && n0 == 0;
     for (int kt = k_lo; kt < k_hi; kt++) {
       unsigned char* sb = lds + buf * STAGE;
       unsigned char* nb = lds + (buf ^ 1) * STAGE;
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
           constexpr int lo = decltype(I)::value * NRD / NMF, hi = (decltype(I)::value + 1) * NRD / NMF;
           if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(0x100, hi - lo, 0);
         });
-        if (do_bg) bias_grad_step(std::integral_constant<int, j & 1>{});
+        if (do_bg && wn == j) bias_grad_step(std::integral_constant<int, j & 1>{});
       });
       // ---- every fragment of this stage is in registers, the next stage has landed: barrier ----
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -340,21 +359,32 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         } else if constexpr (i == 1 || i == 3) { if (nx2_dma) dma(std::integral_constant<int, i / 2>{}, sb, kt2); }
       });
       if constexpr (!(VAR & 2)) { if (nx2_dma) pend_kt = kt2; }
-      if (do_bg) bias_grad_step(std::integral_constant<int, 1>{});
+      if (do_bg && wn == NSTEP - 1) bias_grad_step(std::integral_constant<int, 1>{});
       buf ^= 1;
     }
     // ---- epilogue: the stage just consumed (buf ^ 1) is free (its DMA was held back): the row slab lives there ----
     unsigned char* slab = lds + (buf ^ 1) * STAGE;
     const bool part = p.partial != nullptr;
     if constexpr (BG) {
-      if (do_bg) {                                                  // the two lane halves hold the two halves of every k-step's k's
+      if (do_bg) {     // (workgroup-uniform) lane halves hold the two halves of a k-step's k's, the four wn waves the four k-steps
+        float* red = reinterpret_cast<float*>(slab);                // [wm][wn][128 rows]: 4 KB of the free stage
 #pragma unroll
         for (int i = 0; i < TM; i++) {
           float t = accb[i];
           t += __shfl_xor(t, 32);
-          const int row = m0 + wm * WM + i * T + rl;
-          if (hl == 0 && row < p.M) (part ? p.partial + (size_t)p.split * p.M * p.N + (size_t)z * p.M : p.bias_grad)[row] = t;
+          if (hl == 0) red[(wm * 4 + wn) * WM + i * T + rl] = t;
         }
+        lds_barrier();
+        if (wn == 0) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++) {
+            const int r = h2 * 64 + lane;
+            const float t = ((red[(wm * 4 + 0) * WM + r] + red[(wm * 4 + 1) * WM + r]) + red[(wm * 4 + 2) * WM + r]) + red[(wm * 4 + 3) * WM + r];
+            const int row = m0 + wm * WM + r;
+            if (row < p.M) (part ? p.partial + (size_t)p.split * p.M * p.N + (size_t)z * p.M : p.bias_grad)[row] = t;
+          }
+        }
+        lds_barrier();                                              // the slab rounds below reuse these bytes
       }
 #pragma unroll
       for (int i = 0; i < TM; i++) accb[i] = 0.0f;
@@ -387,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {                             // groups of four consecutive columns
             const int e0 = wn * 64 + j * T + q * 8 + e_hl * 4;
-            const f32x4 bv = bj[j * 4 + q];
+            const f32x4 bv = HAS_BIAS ? bj[HAS_BIAS ? j * 4 + q : 0] : f32x4{0, 0, 0, 0};
             if constexpr (ES == 2) {
               struct alignas(8) B4 { bf16_t e[4]; } v;
 #pragma unroll
@@ -404,6 +434,51 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         }
       }
       lds_barrier();
+      if constexpr (BG && ES == 4) {
+        if (adam_on) {
+          // Optimizer epilogue (include/vct_hip.h, vct_gemm_adam; the same shared update as the 128 x 128 kernel's, csrc/vct_adam_core.h):
+          // the gradient chunk this lane would store is consumed by torch.optim.Adam's update of its four parameters; parameter / moment
+          // vectors of TWO chunks are in flight before the first update (four: 88 spilled registers beside the live accumulators) (a chunk is three dependent HBM round trips otherwise).
+          static_for<CPT / 2>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            float4 ap[2], am[2], av[2];
+            int ae[2]; bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int cid = (h * 2 + u) * NT + e_tid;
+              const int sr = cid / CPRW, c = cid % CPRW;
+              const int row = m0 + (sr / (MTR * T)) * WM + (rd * MTR + ((sr / T) % MTR)) * T + (sr % T), col = n0 + c * 4;
+              ok[u] = row < p.M && col + 4 <= p.N;
+              ae[u] = min(row, p.M - 1) * (int)p.ldc + min(col, max(p.N - 4, 0));      // (M x ldc < 2^31: gemm256_try)
+              ap[u] = *reinterpret_cast<const float4*>(p.adam.param + ae[u]);
+              am[u] = *reinterpret_cast<const float4*>(p.adam.m + ae[u]);
+              av[u] = *reinterpret_cast<const float4*>(p.adam.v + ae[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int cid = (h * 2 + u) * NT + e_tid;
+              const int sr = cid / CPRW, c = cid % CPRW;
+              const f32x4 g = *reinterpret_cast<const f32x4*>(slab + sr * (G256_BN * 4) + ((c ^ (sr & 31)) << 4));
+              if (ok[u]) {
+                float* pp = &ap[u].x; float* mp = &am[u].x; float* vp = &av[u].x;
+#pragma unroll
+                for (int e = 0; e < 4; e++) adam_update(pp[e], g[e], mp[e], vp[e], hc);
+                *reinterpret_cast<float4*>(p.adam.param + ae[u]) = ap[u];
+                *reinterpret_cast<float4*>(p.adam.m + ae[u]) = am[u];
+                *reinterpret_cast<float4*>(p.adam.v + ae[u]) = av[u];
+                if (p.adam.shadow != nullptr) {
+                  const int row = ae[u] / (int)p.ldc, col = ae[u] - row * (int)p.ldc;
+                  ushort4 o;
+                  o.x = f2bf(ap[u].x); o.y = f2bf(ap[u].y); o.z = f2bf(ap[u].z); o.w = f2bf(ap[u].w);
+                  *reinterpret_cast<ushort4*>(p.adam.shadow + (size_t)row * p.adam.ld_shadow + col) = o;
+                }
+                if (p.adam.store_grad) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ae[u]) = g;
+              }
+            }
+          });
+        }
+      }
+      if (!adam_on)
 #pragma unroll 2
       for (int q = 0; q < CPT; q++) {
         const int cid = q * NT + e_tid;
