@@ -89,6 +89,12 @@ template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hip
     vars.push_back({"pipelined v1 (first probe)", [&](TO* c, float* bg) { g32v1_launch<0, 1, bf16_t, 32, 0>(prep(c, bg), st); }});
   else
   vars.push_back({"pipelined, prio", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 1>(prep(c, bg), st); }});
+  if constexpr (!(TA == 0 && TB == 1)) {
+    vars.push_back({"pipelined + L2 prefetch 2", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = 2; g32_launch<TA, TB, TO, 0>(q, st); }});
+    vars.push_back({"pipelined + L2 prefetch 3", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = 3; g32_launch<TA, TB, TO, 0>(q, st); }});
+    vars.push_back({"pipelined + L2 prefetch 4", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = 4; g32_launch<TA, TB, TO, 0>(q, st); }});
+    vars.push_back({"pipelined 8+0+0 + L2 prefetch 3", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = 3; g32_launch<TA, TB, TO, 2>(q, st); }});
+  }
   if constexpr (TA == 1) {
     vars.push_back({"r5, no bias grad", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.bias_grad = nullptr; base_launch<TA, TB, TO>(q, st); }});
     vars.push_back({"pipelined, no bias grad", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.bias_grad = nullptr; g32_launch<TA, TB, TO, 0>(q, st); }});
@@ -105,7 +111,7 @@ template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hip
   std::vector<TO> c0(out_elems), c1(out_elems);
   std::vector<float> g0(M), g1(M);
   hipMemcpy(c0.data(), dC0, out_elems * sizeof(TO), hipMemcpyDeviceToHost); hipMemcpy(g0.data(), dbg0, M * 4, hipMemcpyDeviceToHost);
-  for (size_t v = 0; v < 4; v++) {
+  for (size_t v = 0; v < (TA == 0 && TB == 1 ? 4 : 8); v++) {
     hipMemset(dC1, 0xff, out_elems * sizeof(TO)); hipMemset(dbg1, 0xff, M * 4);
     vars[v].run(dC1, dbg1); hipStreamSynchronize(st);
     const hipError_t e = hipGetLastError();
@@ -148,6 +154,28 @@ template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hip
       const double us = ms * 1e3 / iters;
       printf("[%s] round %d %-32s %8.1f us  %7.1f TF\n", s.name, r, vars[v].name, us, 2.0 * M * N * K / us / 1e6);
     }
+  if constexpr (!(TA == 1 && TB == 0)) {
+    // where a tile's time goes: (label, shader clock) pairs from wave 0 of workgroup 0 (g32_kernel, VAR & 32)
+    long long* dst; hipMalloc(&dst, 800 * 8); 
+    for (int rep = 0; rep < 50; rep++) {
+      hipMemset(dst, 0, 800 * 8);
+      G256P q = prep(dC1, dbg1); q.bias_grad = reinterpret_cast<float*>(dst);
+      if (const char* e = getenv("VCT_PROBE_PF")) q.pf_dist = atoi(e);
+      g32_launch<TA, TB, TO, 32>(q, st); hipStreamSynchronize(st);
+    }
+    std::vector<long long> hs(800); hipMemcpy(hs.data(), dst, 800 * 8, hipMemcpyDeviceToHost);
+    printf("[%s] stamps of workgroup 0 (label:delta cycles since the previous stamp; 0 stage top, 1 k-steps 0-2 done, 2 vmcnt(0) passed, 3 barrier passed, 4 K loop done, 5 slab written, 6 barrier, 7 read-out + stores issued + barrier, 8 stores issued, 9 next stage DMA issued)\n", s.name);
+    long long prev = hs[1], t_tile = hs[1], t4 = 0; int ntile = 0;
+    printf("stamps:\n");
+    for (int i = 0; i < 400 && hs[2 * i + 1] != 0; i++) {
+      if (i < 64 || hs[2 * i] >= 4) printf(" %lld:%lld", hs[2 * i], hs[2 * i + 1] - prev);
+      prev = hs[2 * i + 1];
+      if (hs[2 * i] == 4) t4 = prev;
+      if (hs[2 * i] == 9) { printf("   | K loop %lld epilogue %lld\n", t4 - t_tile, prev - t4); t_tile = prev; ntile++; }
+    }
+    printf("\n");
+    hipFree(dst);
+  }
   hipFree(dA); hipFree(dB); hipFree(dC0); hipFree(dC1); hipFree(dbias); hipFree(dbg0); hipFree(dbg1);
   fflush(stdout);
 }

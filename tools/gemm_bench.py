@@ -45,8 +45,9 @@ def run(name, ta, tb, M, N, K, odt, tile, iters=20, workspace=True):
     if workspace:        # (the engine's layer GEMMs pass none: no split-K)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.reserved = tile
+    d.split_k = int(os.environ.get("VCT_BENCH_SPLIT", "0"))     # 0: the library's own choice
     st = L.stream_ptr()
-    for _ in range(3):
+    for _ in range(int(os.environ.get("VCT_BENCH_WARM", "3"))):     # (a few hundred launches bring an idle part to its sustained clocks)
         L.check(lib.vct_gemm(d, st), name)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -107,6 +108,12 @@ if __name__ == "__main__":
     sel = sys.argv[1:]
     if sel and sel[0] == "--grouped":
         grouped(4864, 3328)
+        sys.exit(0)
+    if sel and sel[0] == "--plan":   # the library's own plan for the named shapes (no vendor leg)
+        for s in SHAPES:
+            if any(x in s[0] for x in sel[1:]):
+                ms, tf = run(*s, 0, iters=int(os.environ.get("VCT_BENCH_ITERS", "30")))
+                print(f"{s[0]:30s} {ms*1e3:7.1f}us {tf:4.0f}TF", flush=True)
         sys.exit(0)
     if sel and sel[0] == "--auto":   # the plan the library picks by itself vs the vendor library
         print(f"{'shape':30s} {'auto':>15s} {'vendor':>15s}")

@@ -28,6 +28,7 @@
 // the stores behind a counted vmcnt changes nothing.
 #include "vct_gemm_bf16_kernel.h"
 #include <cstring>
+#include <cstdio>
 #include <mutex>
 #include <unordered_map>
 
@@ -46,6 +47,7 @@ struct G256P {
   int zmajor;                   // split > 1: K split outermost (tiles that share the A rows of one K range are neighbours)
   int dbg;                      // experiments (VCT_GEMM256_DBG): 1 = no MFMA work, 2 = no operand DMA after the first stage, 4 = no epilogue
   AdamEpiP adam;                // weight-gradient form on g32_kernel only (vct_gemm_adam); param == nullptr: off
+  int pf_dist;                  // g32_kernel: L2 prefetch of the A operand this many K stages ahead (0: off)
 };
 
 constexpr int G256_BM = 256, G256_BN = 256;
@@ -348,6 +350,14 @@ int gemm256_try(const vct_gemm_desc* d, hipStream_t st, bool* used, int* reduce_
   { static const char* oenv = getenv("VCT_GEMM256_ORDER"); p.order = oenv != nullptr ? atoi(oenv) : 1; }
   static const char* denv = getenv("VCT_GEMM256_DBG");
   p.dbg = denv != nullptr ? atoi(denv) : 0;
+  // L2 prefetch distance of the pipelined kernel (K stages; vct_gemm32_kernel.h): the NN form (vocabulary dX) gains 4-8 % alone at 2-4,
+  // the TN form nothing (profiles/r06_g32_prefetch_probe.txt).  VCT_G32_PREFETCH="nn,tn" overrides.
+  {
+    static const char* penv = getenv("VCT_G32_PREFETCH");
+    int pf_nn = 3, pf_tn = 0;
+    if (penv != nullptr) sscanf(penv, "%d,%d", &pf_nn, &pf_tn);
+    p.pf_dist = form == 0 ? pf_nn : (form == 2 ? pf_tn : 0);
+  }
   const long tiles = (long)p.tiles_m * p.tiles_n;
   p.zmajor = 0;
   if (form == 1 && (mask & 8) && d->out_dtype == VCT_BF16 && !d->bias && !d->bias_grad && d->split_k != 1 && d->workspace != nullptr &&

@@ -85,6 +85,8 @@ __device__ __forceinline__ void tail_tile32(unsigned char* img, const bf16_t* __
   }
 }
 
+constexpr int G32_LDS = G256_LDS + 2048;                            // + the prefetch's dump area (512 threads x 4 bytes)
+
 // The caller's G256P (vct_gemm256.hip, which includes this file) is reused: same work-item order, same output conventions.
 template <int TA, int TB, typename TO, int VAR>
 __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
@@ -133,9 +135,16 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
   const int lda32 = (int)p.lda, ldb32 = (int)p.ldb;               // (operands < 2 GiB: g32_eligible)
   const int kstrA = A_MC ? 128 * lda32 : 128, kstrB = B_MC ? 128 * ldb32 : 128;   // bytes per K stage
   int voff[8];
+  int pf_off = 0;                                                  // L2 prefetch of A (below): byte offset of the thread's dword at K offset 0
   auto set_voff = [&](int m0, int n0) {
     int l = lane;
     asm volatile("" : "+v"(l));                                    // opaque: nothing of this is hoisted out of the item loop and kept alive
+    if (p.pf_dist > 0) {                                           // one dword per 64 bytes of the 32 KB A stage = one per thread
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      if constexpr (!A_MC) pf_off = (min(m0 + (t >> 1), p.M - 1) * lda32 + (t & 1) * 32) * 2;
+      else pf_off = ((t >> 3) * lda32 + min(m0 + (t & 7) * 32, ((p.M + 7) & ~7) - 8)) * 2;
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int ci = (q & 3) * 8 + wave;
@@ -159,6 +168,15 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     unsigned char* dst = stage_buf + (q >= 4 ? A_BYTES : 0) + ci * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(q >= 4 ? rsB : rsA, (__attribute__((address_space(3))) void*)dst, 16, voff[q],
                                              kt * (q >= 4 ? kstrB : kstrA), 0, 0);
+  };
+  // L2 prefetch of the A operand's stage `kt`: the vocabulary gradients stream 297 MB of dlogits from HBM once, a stage's DMA is issued
+  // one stage (~1.4 us) before it is consumed and HBM answers in about that time under load -- every stage barrier waited 600-1000
+  // cycles of 3600 for it (tools/g32_probe.hip stamps, profiles/r06_g32_stamps.txt).  A 4-byte LDS-DMA per thread into a dump area
+  // behind the stages touches every 64 bytes of the stage p.pf_dist stages ahead: the real DMA then hits in L2.  It is issued as the
+  // LAST vector-memory instruction in front of the stage barrier, whose wait is vmcnt(1): it never waits for the prefetch itself.
+  auto prefetch_a = [&](int kt) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(lds + 2 * STAGE + wave * 256), 4, pf_off,
+                                             kt * kstrA, 0, 0);
   };
   auto tail_stage = [&](unsigned char* stage_buf, int m0, int n0, int kt) {      // ragged stage: register path, every thread
     tail_tile32<A_MC, NT>(stage_buf, A, p.lda, m0, p.M, kt * BK2, p.K, tid);
@@ -292,6 +310,16 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     adam_on = p.adam.param != nullptr && p.partial == nullptr;
     if (adam_on) hc = adam_consts_uniform(p.adam.hyper, p.adam.step);
   }
+  // (VAR & 32, tools/g32_probe.hip: wave 0 of workgroup 0 logs (label, shader clock) pairs into the buffer p.bias_grad points at)
+  int sidx = 0;
+  auto stamp = [&](int label) {
+    if constexpr ((VAR & 32) != 0) {
+      if (blockIdx.x == 0 && tid == 0 && sidx < 400) {
+        long long* sp = reinterpret_cast<long long*>(p.bias_grad);
+        sp[2 * sidx] = label; sp[2 * sidx + 1] = (long long)clock64(); sidx++;
+      }
+    }
+  };
   int w = w_begin + slot;
   int m0 = 0, z = 0, k_lo = 0, k_hi = 0;
   int buf = 0;
@@ -315,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
       unsigned char* sb = lds + buf * STAGE;
       unsigned char* nb = lds + (buf ^ 1) * STAGE;
       const bool last = kt + 1 == k_hi;
+      stamp(0);
       if (last) load_bias();                                        // in flight under this stage; the barrier's vmcnt(0) covers them
       // ---- k-steps 0 .. 2: MFMAs of step j, reads of step j+1 between them ----
       static_for<NSTEP - 1>([&](auto J) {
@@ -334,9 +363,16 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         if (do_bg && wn == j) bias_grad_step(std::integral_constant<int, j & 1>{});
       });
       // ---- every fragment of this stage is in registers, the next stage has landed: barrier ----
+      stamp(1);
+      if (p.pf_dist > 0) {
+        prefetch_a(min(kt + p.pf_dist, min(k_hi, kt_full) - 1));
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      } else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      stamp(2);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      stamp(3);
       // ---- last k-step: first fragments of stage s+1, MFMAs, DMA of stage s+2 into this buffer between them.  ONE MFMA path: the
       // wave-uniform conditions only guard the small read / DMA blocks (three copies of the step made hipcc shuffle and spill whole
       // accumulators at the joins).  The LAST stage of an item keeps its buffer for the epilogue's row slab: its DMA follows that. ----
@@ -363,6 +399,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
       buf ^= 1;
     }
     // ---- epilogue: the stage just consumed (buf ^ 1) is free (its DMA was held back): the row slab lives there ----
+    stamp(4);
     unsigned char* slab = lds + (buf ^ 1) * STAGE;
     const bool part = p.partial != nullptr;
     if constexpr (BG) {
@@ -408,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
     } else
     static_for<TM / MTR>([&](auto RD) {
       constexpr int rd = decltype(RD)::value;
-      if constexpr (rd > 0) lds_barrier();                          // the slab has been read out by everyone
+      if constexpr (rd > 0) { lds_barrier(); stamp(7); }            // the slab has been read out by everyone
 #pragma unroll
       for (int ii = 0; ii < MTR; ii++) {
         const int sr = (wm * MTR + ii) * T + e_rl;                    // slab row; 16-byte chunk c of row r sits at c ^ (r & 31)
@@ -433,7 +470,9 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
           }
         }
       }
+      stamp(5);
       lds_barrier();
+      stamp(6);
       if constexpr (BG && ES == 4) {
         if (adam_on) {
           // Optimizer epilogue (include/vct_hip.h, vct_gemm_adam; the same shared update as the 128 x 128 kernel's, csrc/vct_adam_core.h):
@@ -498,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         }
       }
     });
+    stamp(8);
     zero_acc();
     // the slab has been read out by everyone: the held-back stage (second stage of the next item) goes into it
     if (have_next) {
@@ -507,14 +547,15 @@ __global__ __launch_bounds__(512, 2) void g32_kernel(const G256P p) {
         else tail_stage(slab, m1, n1, k1_lo + 1);
       }
     }
+    stamp(9);
     m0 = m1; n0 = n1; z = z1; k_lo = k1_lo; k_hi = k1_hi;
   }
 }
 
 template <int TA, int TB, typename TO, int VAR> static int g32_launch(const G256P& p, hipStream_t st) {
   static vct::DynLdsOptIn optin;
-  if (hipError_t e = optin.ensure((const void*)g32_kernel<TA, TB, TO, VAR>, G256_LDS); e != hipSuccess) return (int)e;
-  vct::launch(g32_kernel<TA, TB, TO, VAR>, dim3(persistent_grid(st)), dim3(512), (size_t)G256_LDS, st, p);
+  if (hipError_t e = optin.ensure((const void*)g32_kernel<TA, TB, TO, VAR>, G32_LDS); e != hipSuccess) return (int)e;
+  vct::launch(g32_kernel<TA, TB, TO, VAR>, dim3(persistent_grid(st)), dim3(512), (size_t)G32_LDS, st, p);
   VCT_CHECK_LAUNCH();
   return VCT_OK;
 }
