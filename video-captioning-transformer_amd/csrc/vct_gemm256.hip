@@ -289,9 +289,9 @@ int persistent_grid(hipStream_t st) {
 namespace vct {
 
 // VCT_GEMM32: which forms run on the pipelined kernel (1 = NT, 2 = NN, 4 = TN, 8 = NT split over K).  Default 6: the vocabulary dX
-// (NN, 186-195 -> 157-165 us alone, 0.218 -> 0.182 ms in the step) and the vocabulary dW (TN, with the optimizer epilogue); the NT forms
-// measure equal alone and slower in the step.  gemm256_kernel takes what the pipelined kernel does not
-// (fewer than two full K stages per work item).
+// (NN, 0.218 -> 0.182 ms in the step) and the vocabulary dW (TN, with the optimizer epilogue: 0.333 -> 0.22 ms); the NT form is
+// slower on the vocabulary projection, alone at sustained clocks and in the step.
+// gemm256_kernel takes what the pipelined kernel does not (fewer than two full K stages per work item).
 static bool g32_takes(int form_bit) {
   static const char* env32 = getenv("VCT_GEMM32");
   const int mask32 = env32 != nullptr ? atoi(env32) : 6;

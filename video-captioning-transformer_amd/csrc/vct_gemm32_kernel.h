@@ -36,11 +36,13 @@
 //     wn takes k-step wn of every stage -- and reduced through the free stage buffer at the tile's end (one wave doing all of them
 //     was the tile's critical path); with p.adam set the fp32 read-out of the slab IS the optimizer step (vct_adam_core.h: p / m / v
 //     read and written, bf16 shadow written, the gradient itself stored only on request), two 16-byte chunks in flight per lane.
+//   * L2 prefetch (p.pf_dist, NN form): see prefetch_a below.
 // Measured against gemm256_kernel, same process, same data (tools/g32_probe.hip, profiles/r06_g32_probe_*.txt): NT 4096^3 1190-1250 ->
-// 1250-1300 TF; vocabulary products NT 171-177 -> 161-169 us alone but 0.170 -> 0.188 ms in the step (its burstier LDS traffic loses
-// beside the side stream's kernels: NT stays on gemm256_kernel), NN 218 -> 182 us and TN 333 -> 222 us IN the step (both adopted;
-// VCT_GEMM32 bit mask, default 6 = NN | TN).  Outputs are bit-identical to gemm256_kernel's for NT / NN (same accumulation order); the
-// TN form's bias gradient sums in a different (fixed) order.
+// 1220-1300 TF; vocabulary products at sustained clocks: NT 165-174 -> 178-186 us (its epilogue, 45 % of a tile, is bound by one CU's
+// store path -- profiles/r06_g32_stamps.txt -- and the leaner loop's later DMA issue loses on a tile whose W panel is new every 8
+// stages: NT stays on gemm256_kernel), NN 191-220 -> 150-166 us (0.218 -> 0.182 ms in the step) and TN 185-233 -> 154-171 us
+// (0.333 -> 0.22 ms in the step with the optimizer epilogue): both adopted (VCT_GEMM32 bit mask, default 6 = NN | TN).  Outputs are
+// bit-identical to gemm256_kernel's for NT / NN (same accumulation order); the TN form's bias gradient sums in a different (fixed) order.
 #pragma once
 #include "vct_gemm_bf16_kernel.h"      // (included by vct_gemm256.hip, which defines G256P, G256_STAGE, persistent_grid ... in front of it)
 
