@@ -21,6 +21,7 @@ void replay_note_error(int) {}
 
 #include "g32_kernel_v1.h"
 #include "g32w4_kernel.h"
+#include "g32r_kernel.h"
 using namespace vct;
 
 static uint16_t f2bf_host(float f) {
@@ -85,6 +86,8 @@ template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hip
   auto prep = [&](TO* c, float* bg) { G256P q = p; if (split > 1) q.partial = reinterpret_cast<float*>(c); else q.C = c; if (TA == 1 && TB == 0) q.bias_grad = bg; return q; };
   vars.push_back({"round-5 gemm256", [&](TO* c, float* bg) { base_launch<TA, TB, TO>(prep(c, bg), st); }});
   vars.push_back({"pipelined 32x32x16", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 0>(prep(c, bg), st); }});
+  vars.push_back({"ring of 4 half-stages", [&](TO* c, float* bg) { g32r_launch<TA, TB, TO, 0>(prep(c, bg), st); }});
+  vars.push_back({"ring + L2 prefetch 6", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = 6; g32r_launch<TA, TB, TO, 0>(q, st); }});
   vars.push_back({"pipelined, 4 waves x 128x128", [&](TO* c, float* bg) { G256P q = prep(c, bg); q.pf_dist = (TA == 0 && TB == 0) ? 3 : 0; g32w4_launch<TA, TB, TO, 128>(q, st); }});
   vars.push_back({"pipelined, DMA in one k-step", [&](TO* c, float* bg) { g32_launch<TA, TB, TO, 2>(prep(c, bg), st); }});
   if constexpr (TA == 0 && TB == 1 && sizeof(TO) == 2)
@@ -113,7 +116,7 @@ template <int TA, int TB, typename TO> static void run_shape(const Shape& s, hip
   std::vector<TO> c0(out_elems), c1(out_elems);
   std::vector<float> g0(M), g1(M);
   hipMemcpy(c0.data(), dC0, out_elems * sizeof(TO), hipMemcpyDeviceToHost); hipMemcpy(g0.data(), dbg0, M * 4, hipMemcpyDeviceToHost);
-  for (size_t v = 0; v < (TA == 0 && TB == 1 ? 5 : 9); v++) {
+  for (size_t v = 0; v < (TA == 0 && TB == 1 ? 7 : 11); v++) {
     hipMemset(dC1, 0xff, out_elems * sizeof(TO)); hipMemset(dbg1, 0xff, M * 4);
     vars[v].run(dC1, dbg1); hipStreamSynchronize(st);
     const hipError_t e = hipGetLastError();
